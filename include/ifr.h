@@ -1,0 +1,130 @@
+/*
+ * ifr.h -- C ABI of the MI355X-native scoring + ranking-evaluation library (libifr.so).
+ *
+ * The reference (Informfully/Recommenders, a Cornac fork) exposes this hot path as a
+ * duck-typed Python class API, not as a C FFI.  Each entry point
+ * below therefore cites the reference *Python* interface it replaces (file:line relative
+ * to the reference root); INTEGRATION.md shows the ctypes stub a maintainer adds.
+ *
+ * Conventions
+ *  - extern "C", opaque handle, int status return (0 = IFR_OK, <0 = error; the text of the
+ *    last error is available from ifr_last_error).  No exceptions cross the boundary.
+ *  - "dev" pointers must be device memory on the handle's GPU; "any" pointers may be host
+ *    or device memory (copied with hipMemcpyDefault during the call; borrowed only for its
+ *    duration).  `stream` is a hipStream_t passed as void* (NULL = the default stream).
+ *  - One host thread per handle; a handle is not re-entrant.  Calls on one handle that
+ *    use the same stream are ordered by it.
+ *  - Item ids are int32, user ids int32, CSR row pointers int64, CSR column indices int32
+ *    sorted ascending within a row (what scipy.sparse.csr_matrix.sort_indices() yields;
+ *    the reference's Dataset.csr_matrix is sorted, cornac/data/dataset.py:229-238).
+ */
+#ifndef IFR_H
+#define IFR_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ifr_handle_s *ifr_handle;
+
+enum {
+    IFR_OK = 0,
+    IFR_ERR_ARG = -1,        /* bad argument (null pointer, size, unsupported k/K) */
+    IFR_ERR_STATE = -2,      /* called before the data it needs was set            */
+    IFR_ERR_HIP = -3,        /* a HIP runtime call failed                          */
+    IFR_ERR_NOMEM = -4       /* device allocation failed                           */
+};
+
+#define IFR_MAX_FACTORS 128  /* latent dimension k supported by the fused kernel   */
+#define IFR_MAX_TOPK 32      /* K supported by the fused score+select kernel       */
+
+/* Library / handle life cycle.  (No reference counterpart: the reference keeps model
+ * parameters as NumPy arrays on the Recommender object, cornac/models/recommender.py:160-168.) */
+const char *ifr_version(void);
+int ifr_create(ifr_handle *out, int device_id);
+int ifr_destroy(ifr_handle h);
+const char *ifr_last_error(ifr_handle h);
+
+/* Launch tuning (no reference counterpart).  "chunks": item chunks per user tile in the fused
+ * kernel (0 = heuristic); "target_blocks": workgroups the heuristic aims for. */
+int ifr_set_option(ifr_handle h, const char *name, int64_t value);
+
+/* Model parameters of a dot-product model: score(u,i) = (ibase[i] + ubase[u]) + <U[u], V[i]>.
+ * Replaces the parameter reads of BPR.score (cornac/models/bpr/recom_bpr.pyx:290-293:
+ * ibase = i_biases), MF.score (cornac/models/mf/recom_mf.py:275-280: ibase = fl(mu + Bi),
+ * ubase = Bu) and WMF.score (cornac/models/wmf/recom_wmf.py:236-237: both NULL).
+ * U: [n_users][k], V: [n_items][k] row-major fp32 ("any" pointers).  k <= IFR_MAX_FACTORS. */
+int ifr_set_factors(ifr_handle h, const float *U, int64_t n_users, const float *V, int64_t n_items,
+                    int k, const float *ubase, const float *ibase);
+
+/* Per-user exclusion lists = items that must not be ranked: (train U validation positives)
+ * minus test positives, already filtered by rating_threshold and clipped to [0, n_items)
+ * (cornac/eval_methods/base_method.py:246-251, 265-283; SURVEY.md Appendix B rules 2-3).
+ * n_rows may be smaller than n_users: users >= n_rows have no exclusions (:266-270).
+ * "any" pointers.  Pass nnz = 0 / NULLs to clear. */
+int ifr_set_exclusion_csr(ifr_handle h, const int64_t *indptr, const int32_t *indices,
+                          int64_t n_rows, int64_t nnz);
+
+/* Per-user ground truth = test positives (rating >= threshold, item < n_items), the gt_pos of
+ * cornac/eval_methods/base_method.py:257-263, 282.  "any" pointers. */
+int ifr_set_truth_csr(ifr_handle h, const int64_t *indptr, const int32_t *indices,
+                      int64_t n_rows, int64_t nnz);
+
+/* Fused scoring + exclusion + top-K selection for a batch of users.  Replaces the head of
+ * Recommender.rank (cornac/models/recommender.py:624-652: score, candidate gather,
+ * argsort/argpartition) for every listed user at once.  Order: score descending, item index
+ * ascending on ties.  out_ids/out_scores: dev [n][K]; unfilled slots (fewer than K
+ * candidates) hold id -1 / score -inf.  1 <= K <= IFR_MAX_TOPK.  user_ids: dev [n]. */
+int ifr_rank_topk(ifr_handle h, const int32_t *user_ids, int64_t n, int K,
+                  int32_t *out_ids, float *out_scores, void *stream);
+
+/* Ranking metrics from top-K lists against the truth CSR.  Replaces NDCG.compute,
+ * Precision.compute and Recall.compute (cornac/metrics/ranking.py:100-123, 329-349, 366-386)
+ * and the per-user loop + mean of ranking_eval (cornac/eval_methods/base_method.py:291-303).
+ * ks: host array of n_k cut-offs, each 1 <= ks[j] <= K.  out_per_user: dev [n][3*n_k]
+ * (ndcg, recall, precision per cut-off; NaN rows for users without a test positive, which
+ * the reference skips, :258-259).  evaluated: dev [n] 0/1.  out_sums: dev [3*n_k + 1] =
+ * column sums over evaluated users followed by their count (the operands of one
+ * all-reduce in the multi-GPU path). */
+int ifr_eval_topk_metrics(ifr_handle h, const int32_t *user_ids, int64_t n,
+                          const int32_t *topk_ids, int K, const int32_t *ks, int n_k,
+                          double *out_per_user, int32_t *evaluated, double *out_sums, void *stream);
+
+/* Full score rows for a batch of users (bit-identical to the scores the fused kernel ranks).
+ * Replaces Recommender.score(user_idx) (cornac/models/recommender.py:480-498) /
+ * item_scores of rank (:643).  out: dev [n][ld] fp32, ld >= n_items. */
+int ifr_score_dense(ifr_handle h, const int32_t *user_ids, int64_t n, float *out, int64_t ld,
+                    void *stream);
+
+/* AUC per user from dense score rows.  Replaces AUC.compute (cornac/metrics/ranking.py:473-485)
+ * with gt_neg = candidates - gt_pos, candidates = [0,n_items) - exclusions
+ * (base_method.py:281-283).  scores: dev [n][ld]; out_auc: dev [n] (NaN without positives). */
+int ifr_auc_dense(ifr_handle h, const int32_t *user_ids, int64_t n, const float *scores,
+                  int64_t ld, double *out_auc, void *stream);
+
+/* Full ranking of dense score rows: every candidate ([0,n_items) minus exclusions) ordered by
+ * score descending, item index ascending.  Replaces the k == -1 branch of Recommender.rank
+ * (cornac/models/recommender.py:651-652).  out_ids: dev [n][ld] int32 (first n_cand[i] entries
+ * valid, rest -1); n_cand: dev [n]. */
+int ifr_rank_full(ifr_handle h, const int32_t *user_ids, int64_t n, const float *scores,
+                  int64_t ld, int32_t *out_ids, int32_t *n_cand, void *stream);
+
+/* Kernel timing with HIP events on the launch stream (used by bench.py for the roofline
+ * figure; no reference counterpart).  After ifr_profile_enable(h, 1) every ifr_rank_topk
+ * records events around its fused score+select kernel; ifr_profile_read synchronises those
+ * events and returns the summed kernel milliseconds, launch count and users*items scored
+ * since the last read. */
+int ifr_profile_enable(ifr_handle h, int on);
+int ifr_profile_read(ifr_handle h, double *kernel_ms, int64_t *launches, double *pairs_scored);
+
+/* The k-index order of the fp32 fma chain the kernels accumulate each dot product in
+ * (perm[t] = factor index consumed at chain step t, for the padded dimension the handle
+ * uses); lets a CPU checker reproduce scores bit-for-bit.  perm: host [*n], *n = padded k. */
+int ifr_factor_chain_order(ifr_handle h, int32_t *perm, int *n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IFR_H */

@@ -1,0 +1,5 @@
+"""MI355X-native candidate scoring + ranking evaluation (drop-in for the hot path of
+Informfully/Recommenders, a Cornac fork).  See DESIGN.md and INTEGRATION.md."""
+from .engine import HipScorer, IfrError  # noqa: F401
+
+__version__ = "0.1.0"

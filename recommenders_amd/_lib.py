@@ -1,0 +1,62 @@
+"""ctypes binding of libifr.so (the C ABI declared in include/ifr.h).
+
+The library is built in-tree by ``recommenders_amd/csrc/Makefile`` (see
+``__graft_entry__.build``).  There is no CPU fallback: if the shared object is
+missing, loading raises, and every compute entry point needs a GPU.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libifr.so")
+
+c_i32p = ctypes.POINTER(ctypes.c_int32)
+c_i64p = ctypes.POINTER(ctypes.c_int64)
+c_f32p = ctypes.POINTER(ctypes.c_float)
+c_f64p = ctypes.POINTER(ctypes.c_double)
+vp = ctypes.c_void_p
+
+# name -> (restype, argtypes); one row per declaration in include/ifr.h
+SIGNATURES = {
+    "ifr_version": (ctypes.c_char_p, []),
+    "ifr_create": (ctypes.c_int, [ctypes.POINTER(vp), ctypes.c_int]),
+    "ifr_destroy": (ctypes.c_int, [vp]),
+    "ifr_last_error": (ctypes.c_char_p, [vp]),
+    "ifr_set_option": (ctypes.c_int, [vp, ctypes.c_char_p, ctypes.c_int64]),
+    "ifr_set_factors": (ctypes.c_int, [vp, vp, ctypes.c_int64, vp, ctypes.c_int64, ctypes.c_int, vp, vp]),
+    "ifr_set_exclusion_csr": (ctypes.c_int, [vp, vp, vp, ctypes.c_int64, ctypes.c_int64]),
+    "ifr_set_truth_csr": (ctypes.c_int, [vp, vp, vp, ctypes.c_int64, ctypes.c_int64]),
+    "ifr_rank_topk": (ctypes.c_int, [vp, vp, ctypes.c_int64, ctypes.c_int, vp, vp, vp]),
+    "ifr_eval_topk_metrics": (ctypes.c_int, [vp, vp, ctypes.c_int64, vp, ctypes.c_int, c_i32p, ctypes.c_int,
+                                             vp, vp, vp, vp]),
+    "ifr_score_dense": (ctypes.c_int, [vp, vp, ctypes.c_int64, vp, ctypes.c_int64, vp]),
+    "ifr_auc_dense": (ctypes.c_int, [vp, vp, ctypes.c_int64, vp, ctypes.c_int64, vp, vp]),
+    "ifr_rank_full": (ctypes.c_int, [vp, vp, ctypes.c_int64, vp, ctypes.c_int64, vp, vp, vp]),
+    "ifr_profile_enable": (ctypes.c_int, [vp, ctypes.c_int]),
+    "ifr_profile_read": (ctypes.c_int, [vp, c_f64p, c_i64p, c_f64p]),
+    "ifr_factor_chain_order": (ctypes.c_int, [vp, c_i32p, ctypes.POINTER(ctypes.c_int)]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libifr.so (after torch, so that both share one HIP runtime) and bind signatures."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build it with `make -C recommenders_amd/csrc` "
+            "(or `python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback.")
+    try:
+        import torch  # noqa: F401  (loads libamdhip64 first; libifr then binds to the same runtime)
+    except ImportError:
+        pass
+    lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib

@@ -1,0 +1,437 @@
+// ifr_api.hip -- C ABI (include/ifr.h) over the kernels in ifr_kernels.h / ifr_aux.hip.
+// Host side: owns device copies of the model and CSR data, picks the launch geometry,
+// launches on the caller's stream.  No torch types; PyTorch only supplies device buffers.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/ifr.h"
+#include "ifr_kernels.h"
+
+namespace ifr {
+// implemented in ifr_aux.hip
+int launch_auc(const float *scores, int64_t ld, const int32_t *user_ids, int64_t n, int n_items,
+               const int64_t *ex_ptr, const int32_t *ex_idx, int64_t ex_rows,
+               const int64_t *tr_ptr, const int32_t *tr_idx, int64_t tr_rows,
+               double *out, hipStream_t stream);
+int launch_rank_full(const float *scores, int64_t ld, const int32_t *user_ids, int64_t n, int n_items,
+                     const int64_t *ex_ptr, const int32_t *ex_idx, int64_t ex_rows,
+                     int32_t *out_ids, int32_t *n_cand, void **ws, size_t *ws_bytes, hipStream_t stream);
+}  // namespace ifr
+
+struct ifr_handle_s {
+    int device = 0;
+    std::string err;
+    // model
+    float *U = nullptr, *V = nullptr, *ibase = nullptr, *ubase = nullptr;
+    int64_t n_users = 0, n_items = 0;
+    int k = 0, KD = 0, n_tiles = 0;
+    bool has_base = false;
+    // exclusions: raw CSR (AUC / full rank) + tile-encoded lists (fused kernel)
+    int64_t *ex_ptr = nullptr;
+    int32_t *ex_idx = nullptr, *ex_cnt = nullptr, *ex_tile = nullptr;
+    uint32_t *ex_mask = nullptr;
+    int64_t ex_rows = 0, ex_nnz = 0;
+    // truth
+    int64_t *tr_ptr = nullptr;
+    int32_t *tr_idx = nullptr;
+    int64_t tr_rows = 0, tr_nnz = 0;
+    int tr_max_row = 0;
+    // workspaces (grow-only)
+    void *ws_part = nullptr; size_t ws_part_bytes = 0;
+    void *ws_met = nullptr; size_t ws_met_bytes = 0;
+    void *ws_sort = nullptr; size_t ws_sort_bytes = 0;
+    double *discount = nullptr;
+    // tuning
+    int opt_chunks = 0;          // 0 = heuristic
+    int opt_target_blocks = 4096;
+    // profiling
+    bool prof = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_used, ev_free;
+    double prof_pairs = 0.0;
+};
+
+namespace {
+
+int fail(ifr_handle h, int code, const std::string &msg)
+{
+    if (h) h->err = msg;
+    return code;
+}
+
+#define IFR_HIP(h, call)                                                                       \
+    do {                                                                                       \
+        hipError_t e_ = (call);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return fail(h, e_ == hipErrorOutOfMemory ? IFR_ERR_NOMEM : IFR_ERR_HIP,            \
+                        std::string(#call) + ": " + hipGetErrorString(e_));                   \
+    } while (0)
+
+template <typename T>
+void dfree(T *&p)
+{
+    if (p) { (void)hipFree(p); p = nullptr; }
+}
+
+int grow(ifr_handle h, void **p, size_t *have, size_t need)
+{
+    if (*have >= need) return IFR_OK;
+    if (*p) { (void)hipFree(*p); *p = nullptr; *have = 0; }
+    IFR_HIP(h, hipMalloc(p, need));
+    *have = need;
+    return IFR_OK;
+}
+
+int pad_k(int k) { return k <= 32 ? 32 : (k <= 64 ? 64 : 128); }
+
+void pick_chunks(ifr_handle h, int64_t n, int *chunk_tiles, int *n_chunks)
+{
+    const int64_t n_ut = (n + ifr::USERS_PER_BLOCK - 1) / ifr::USERS_PER_BLOCK;
+    int64_t c = h->opt_chunks > 0 ? h->opt_chunks : (h->opt_target_blocks + n_ut - 1) / n_ut;
+    const int64_t max_c = std::max<int64_t>(1, std::min<int64_t>(64, h->n_tiles / 16));
+    c = std::max<int64_t>(1, std::min(c, max_c));
+    *chunk_tiles = (int)((h->n_tiles + c - 1) / c);
+    *n_chunks = (h->n_tiles + *chunk_tiles - 1) / *chunk_tiles;
+}
+
+template <int KD, int KL>
+void launch_topk(bool has_base, const ifr::TopkParams &p, int grid, hipStream_t s)
+{
+    if (has_base) hipLaunchKernelGGL((ifr::score_topk_kernel<KD, KL, true>), dim3(grid), dim3(ifr::BLOCK), 0, s, p);
+    else hipLaunchKernelGGL((ifr::score_topk_kernel<KD, KL, false>), dim3(grid), dim3(ifr::BLOCK), 0, s, p);
+}
+
+template <int KL>
+void launch_topk_kd(int KD, bool has_base, const ifr::TopkParams &p, int grid, hipStream_t s)
+{
+    if (KD == 32) launch_topk<32, KL>(has_base, p, grid, s);
+    else if (KD == 64) launch_topk<64, KL>(has_base, p, grid, s);
+    else launch_topk<128, KL>(has_base, p, grid, s);
+}
+
+template <int KD>
+void launch_dense(bool has_base, const ifr::DenseParams &p, int grid, hipStream_t s)
+{
+    if (has_base) hipLaunchKernelGGL((ifr::score_dense_kernel<KD, true>), dim3(grid), dim3(ifr::BLOCK), 0, s, p);
+    else hipLaunchKernelGGL((ifr::score_dense_kernel<KD, false>), dim3(grid), dim3(ifr::BLOCK), 0, s, p);
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *ifr_version(void) { return "ifr 0.1 (gfx950)"; }
+
+int ifr_create(ifr_handle *out, int device_id)
+{
+    if (!out) return IFR_ERR_ARG;
+    *out = nullptr;
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || device_id < 0 || device_id >= n_dev) return IFR_ERR_HIP;
+    if (hipSetDevice(device_id) != hipSuccess) return IFR_ERR_HIP;
+    ifr_handle h = new ifr_handle_s();
+    h->device = device_id;
+    double tab[IFR_MAX_TOPK];
+    for (int i = 0; i < IFR_MAX_TOPK; ++i) tab[i] = 1.0 / std::log2((double)i + 2.0);
+    if (hipMalloc((void **)&h->discount, sizeof(tab)) != hipSuccess ||
+        hipMemcpy(h->discount, tab, sizeof(tab), hipMemcpyHostToDevice) != hipSuccess) {
+        delete h;
+        return IFR_ERR_HIP;
+    }
+    if (const char *e = getenv("IFR_CHUNKS")) h->opt_chunks = atoi(e);
+    if (const char *e = getenv("IFR_TARGET_BLOCKS")) h->opt_target_blocks = std::max(1, atoi(e));
+    *out = h;
+    return IFR_OK;
+}
+
+int ifr_destroy(ifr_handle h)
+{
+    if (!h) return IFR_ERR_ARG;
+    (void)hipSetDevice(h->device);
+    dfree(h->U); dfree(h->V); dfree(h->ibase); dfree(h->ubase);
+    dfree(h->ex_ptr); dfree(h->ex_idx); dfree(h->ex_cnt); dfree(h->ex_tile); dfree(h->ex_mask);
+    dfree(h->tr_ptr); dfree(h->tr_idx); dfree(h->discount);
+    dfree(h->ws_part); dfree(h->ws_met); dfree(h->ws_sort);
+    for (auto &e : h->ev_used) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    for (auto &e : h->ev_free) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    delete h;
+    return IFR_OK;
+}
+
+const char *ifr_last_error(ifr_handle h) { return h ? h->err.c_str() : "null handle"; }
+
+int ifr_set_option(ifr_handle h, const char *name, int64_t value)
+{
+    if (!h || !name) return IFR_ERR_ARG;
+    if (!strcmp(name, "chunks")) h->opt_chunks = (int)value;
+    else if (!strcmp(name, "target_blocks")) h->opt_target_blocks = (int)std::max<int64_t>(1, value);
+    else return fail(h, IFR_ERR_ARG, std::string("unknown option ") + name);
+    return IFR_OK;
+}
+
+int ifr_set_factors(ifr_handle h, const float *U, int64_t n_users, const float *V, int64_t n_items,
+                    int k, const float *ubase, const float *ibase)
+{
+    if (!h) return IFR_ERR_ARG;
+    if (!U || !V || n_users <= 0 || n_items <= 0 || k <= 0) return fail(h, IFR_ERR_ARG, "ifr_set_factors: null/empty input");
+    if (k > IFR_MAX_FACTORS) return fail(h, IFR_ERR_ARG, "ifr_set_factors: k > IFR_MAX_FACTORS (128)");
+    if (n_items > (int64_t)1 << 30) return fail(h, IFR_ERR_ARG, "ifr_set_factors: n_items too large");
+    IFR_HIP(h, hipSetDevice(h->device));
+    dfree(h->U); dfree(h->V); dfree(h->ibase); dfree(h->ubase);
+    const int KD = pad_k(k);
+    const int n_tiles = (int)((n_items + ifr::TILE_I - 1) / ifr::TILE_I);
+    const int64_t v_rows = (int64_t)(n_tiles + 1) * ifr::TILE_I;
+    IFR_HIP(h, hipMalloc((void **)&h->U, sizeof(float) * n_users * KD));
+    IFR_HIP(h, hipMalloc((void **)&h->V, sizeof(float) * v_rows * KD));
+    IFR_HIP(h, hipMalloc((void **)&h->ibase, sizeof(float) * v_rows));
+    IFR_HIP(h, hipMalloc((void **)&h->ubase, sizeof(float) * n_users));
+    IFR_HIP(h, hipMemset(h->U, 0, sizeof(float) * n_users * KD));
+    IFR_HIP(h, hipMemset(h->V, 0, sizeof(float) * v_rows * KD));
+    IFR_HIP(h, hipMemset(h->ibase, 0, sizeof(float) * v_rows));
+    IFR_HIP(h, hipMemset(h->ubase, 0, sizeof(float) * n_users));
+    IFR_HIP(h, hipMemcpy2D(h->U, sizeof(float) * KD, U, sizeof(float) * k, sizeof(float) * k, n_users, hipMemcpyDefault));
+    IFR_HIP(h, hipMemcpy2D(h->V, sizeof(float) * KD, V, sizeof(float) * k, sizeof(float) * k, n_items, hipMemcpyDefault));
+    if (ibase) IFR_HIP(h, hipMemcpy(h->ibase, ibase, sizeof(float) * n_items, hipMemcpyDefault));
+    if (ubase) IFR_HIP(h, hipMemcpy(h->ubase, ubase, sizeof(float) * n_users, hipMemcpyDefault));
+    h->has_base = (ibase != nullptr) || (ubase != nullptr);
+    h->n_users = n_users; h->n_items = n_items; h->k = k; h->KD = KD; h->n_tiles = n_tiles;
+    // CSR data set for another catalogue size would index out of range
+    return IFR_OK;
+}
+
+static int copy_csr(ifr_handle h, const int64_t *indptr, const int32_t *indices, int64_t n_rows, int64_t nnz,
+                    int64_t **d_ptr, int32_t **d_idx, std::vector<int64_t> *host_ptr)
+{
+    dfree(*d_ptr); dfree(*d_idx);
+    host_ptr->assign(n_rows + 1, 0);
+    IFR_HIP(h, hipMemcpy(host_ptr->data(), indptr, sizeof(int64_t) * (n_rows + 1), hipMemcpyDefault));
+    if ((*host_ptr)[0] != 0 || (*host_ptr)[n_rows] != nnz) return fail(h, IFR_ERR_ARG, "CSR: indptr[0] != 0 or indptr[n_rows] != nnz");
+    for (int64_t r = 0; r < n_rows; ++r)
+        if ((*host_ptr)[r + 1] < (*host_ptr)[r]) return fail(h, IFR_ERR_ARG, "CSR: indptr not monotone");
+    IFR_HIP(h, hipMalloc((void **)d_ptr, sizeof(int64_t) * (n_rows + 1)));
+    IFR_HIP(h, hipMalloc((void **)d_idx, sizeof(int32_t) * std::max<int64_t>(nnz, 1)));
+    IFR_HIP(h, hipMemcpy(*d_ptr, host_ptr->data(), sizeof(int64_t) * (n_rows + 1), hipMemcpyHostToDevice));
+    if (nnz > 0) IFR_HIP(h, hipMemcpy(*d_idx, indices, sizeof(int32_t) * nnz, hipMemcpyDefault));
+    return IFR_OK;
+}
+
+int ifr_set_exclusion_csr(ifr_handle h, const int64_t *indptr, const int32_t *indices, int64_t n_rows, int64_t nnz)
+{
+    if (!h) return IFR_ERR_ARG;
+    IFR_HIP(h, hipSetDevice(h->device));
+    dfree(h->ex_ptr); dfree(h->ex_idx); dfree(h->ex_cnt); dfree(h->ex_tile); dfree(h->ex_mask);
+    h->ex_rows = 0; h->ex_nnz = 0;
+    if (n_rows <= 0 || !indptr) return IFR_OK;
+    if (nnz > 0 && !indices) return fail(h, IFR_ERR_ARG, "ifr_set_exclusion_csr: null indices");
+    if (h->n_items <= 0) return fail(h, IFR_ERR_STATE, "ifr_set_exclusion_csr: call ifr_set_factors first");
+    std::vector<int64_t> hp;
+    int rc = copy_csr(h, indptr, indices, n_rows, nnz, &h->ex_ptr, &h->ex_idx, &hp);
+    if (rc) return rc;
+    IFR_HIP(h, hipMalloc((void **)&h->ex_cnt, sizeof(int32_t) * n_rows));
+    IFR_HIP(h, hipMalloc((void **)&h->ex_tile, sizeof(int32_t) * std::max<int64_t>(nnz, 1)));
+    IFR_HIP(h, hipMalloc((void **)&h->ex_mask, sizeof(uint32_t) * std::max<int64_t>(nnz, 1)));
+    const int grid = (int)((n_rows + 255) / 256);
+    hipLaunchKernelGGL(ifr::encode_exclusions_kernel, dim3(grid), dim3(256), 0, 0, h->ex_ptr, h->ex_idx, n_rows,
+                       (int)h->n_items, h->ex_cnt, h->ex_tile, h->ex_mask);
+    IFR_HIP(h, hipGetLastError());
+    IFR_HIP(h, hipDeviceSynchronize());
+    h->ex_rows = n_rows; h->ex_nnz = nnz;
+    return IFR_OK;
+}
+
+int ifr_set_truth_csr(ifr_handle h, const int64_t *indptr, const int32_t *indices, int64_t n_rows, int64_t nnz)
+{
+    if (!h) return IFR_ERR_ARG;
+    IFR_HIP(h, hipSetDevice(h->device));
+    dfree(h->tr_ptr); dfree(h->tr_idx);
+    h->tr_rows = 0; h->tr_nnz = 0; h->tr_max_row = 0;
+    if (n_rows <= 0 || !indptr) return IFR_OK;
+    if (nnz > 0 && !indices) return fail(h, IFR_ERR_ARG, "ifr_set_truth_csr: null indices");
+    std::vector<int64_t> hp;
+    int rc = copy_csr(h, indptr, indices, n_rows, nnz, &h->tr_ptr, &h->tr_idx, &hp);
+    if (rc) return rc;
+    int64_t mx = 0;
+    for (int64_t r = 0; r < n_rows; ++r) mx = std::max(mx, hp[r + 1] - hp[r]);
+    h->tr_rows = n_rows; h->tr_nnz = nnz; h->tr_max_row = (int)mx;
+    return IFR_OK;
+}
+
+int ifr_rank_topk(ifr_handle h, const int32_t *user_ids, int64_t n, int K, int32_t *out_ids, float *out_scores, void *stream)
+{
+    if (!h) return IFR_ERR_ARG;
+    if (!h->U) return fail(h, IFR_ERR_STATE, "ifr_rank_topk: factors not set");
+    if (n == 0) return IFR_OK;
+    if (!user_ids || !out_ids || !out_scores || n < 0) return fail(h, IFR_ERR_ARG, "ifr_rank_topk: null/negative argument");
+    if (K < 1 || K > IFR_MAX_TOPK) return fail(h, IFR_ERR_ARG, "ifr_rank_topk: K must be in [1, 32]");
+    IFR_HIP(h, hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)stream;
+    const int KL = K <= 16 ? 16 : 32;
+    int chunk_tiles, n_chunks;
+    pick_chunks(h, n, &chunk_tiles, &n_chunks);
+    const int64_t n_ut = (n + ifr::USERS_PER_BLOCK - 1) / ifr::USERS_PER_BLOCK;
+    const int64_t grid = n_ut * n_chunks;
+    if (grid > 0x7fffffff) return fail(h, IFR_ERR_ARG, "ifr_rank_topk: batch too large, split the user list");
+    const size_t entries = (size_t)n * n_chunks * 2 * KL;
+    int rc = grow(h, &h->ws_part, &h->ws_part_bytes, entries * 8);
+    if (rc) return rc;
+    ifr::TopkParams p;
+    p.U = h->U; p.V = h->V; p.ibase = h->ibase; p.ubase = h->ubase;
+    p.user_ids = user_ids; p.n = n; p.n_items = (int)h->n_items; p.n_tiles = h->n_tiles;
+    p.chunk_tiles = chunk_tiles; p.n_chunks = n_chunks; p.K = K;
+    p.ex_ptr = h->ex_ptr; p.ex_cnt = h->ex_cnt; p.ex_tile = h->ex_tile; p.ex_mask = h->ex_mask; p.ex_rows = h->ex_rows;
+    p.part_scores = (float *)h->ws_part;
+    p.part_ids = (int32_t *)((char *)h->ws_part + entries * 4);
+
+    std::pair<hipEvent_t, hipEvent_t> ev;
+    if (h->prof) {
+        if (!h->ev_free.empty()) { ev = h->ev_free.back(); h->ev_free.pop_back(); }
+        else { IFR_HIP(h, hipEventCreate(&ev.first)); IFR_HIP(h, hipEventCreate(&ev.second)); }
+        IFR_HIP(h, hipEventRecord(ev.first, s));
+    }
+    if (KL == 16) launch_topk_kd<16>(h->KD, h->has_base, p, (int)grid, s);
+    else launch_topk_kd<32>(h->KD, h->has_base, p, (int)grid, s);
+    if (h->prof) {
+        IFR_HIP(h, hipEventRecord(ev.second, s));
+        h->ev_used.push_back(ev);
+        h->prof_pairs += (double)n * (double)h->n_items;
+    }
+    IFR_HIP(h, hipGetLastError());
+    const size_t smem = (size_t)n_chunks * 2 * KL * 8;
+    if (KL == 16)
+        hipLaunchKernelGGL((ifr::merge_topk_kernel<16>), dim3((unsigned)n), dim3(64), smem, s, p.part_scores, p.part_ids,
+                           n, n_chunks * 2, K, out_ids, out_scores);
+    else
+        hipLaunchKernelGGL((ifr::merge_topk_kernel<32>), dim3((unsigned)n), dim3(64), smem, s, p.part_scores, p.part_ids,
+                           n, n_chunks * 2, K, out_ids, out_scores);
+    IFR_HIP(h, hipGetLastError());
+    return IFR_OK;
+}
+
+int ifr_eval_topk_metrics(ifr_handle h, const int32_t *user_ids, int64_t n, const int32_t *topk_ids, int K,
+                          const int32_t *ks, int n_k, double *out_per_user, int32_t *evaluated, double *out_sums,
+                          void *stream)
+{
+    if (!h) return IFR_ERR_ARG;
+    if (!h->tr_ptr) return fail(h, IFR_ERR_STATE, "ifr_eval_topk_metrics: truth CSR not set");
+    if (!user_ids || !topk_ids || !ks || !out_per_user || !evaluated || !out_sums || n <= 0)
+        return fail(h, IFR_ERR_ARG, "ifr_eval_topk_metrics: null/empty argument");
+    if (K < 1 || K > IFR_MAX_TOPK || n_k < 1 || n_k > ifr::MAX_KS)
+        return fail(h, IFR_ERR_ARG, "ifr_eval_topk_metrics: K in [1,32], n_k in [1,8]");
+    for (int q = 0; q < n_k; ++q)
+        if (ks[q] < 1 || ks[q] > K) return fail(h, IFR_ERR_ARG, "ifr_eval_topk_metrics: cut-off outside [1, K]");
+    IFR_HIP(h, hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)stream;
+    const int grid = (int)((n + ifr::BLOCK - 1) / ifr::BLOCK);
+    const int ncol1 = 3 * n_k + 1;
+    int rc = grow(h, &h->ws_met, &h->ws_met_bytes, sizeof(double) * (size_t)grid * ncol1);
+    if (rc) return rc;
+    ifr::MetricParams p;
+    p.user_ids = user_ids; p.n = n; p.topk = topk_ids; p.K = K; p.n_k = n_k;
+    for (int q = 0; q < ifr::MAX_KS; ++q) p.ks[q] = q < n_k ? ks[q] : 0;
+    p.tr_ptr = h->tr_ptr; p.tr_idx = h->tr_idx; p.tr_rows = h->tr_rows;
+    p.discount = h->discount; p.per_user = out_per_user; p.evaluated = evaluated;
+    p.block_sums = (double *)h->ws_met;
+    hipLaunchKernelGGL(ifr::metrics_kernel, dim3(grid), dim3(ifr::BLOCK), 0, s, p);
+    hipLaunchKernelGGL(ifr::reduce_sums_kernel, dim3(1), dim3(64), 0, s, p.block_sums, grid, ncol1, out_sums);
+    IFR_HIP(h, hipGetLastError());
+    return IFR_OK;
+}
+
+int ifr_score_dense(ifr_handle h, const int32_t *user_ids, int64_t n, float *out, int64_t ld, void *stream)
+{
+    if (!h) return IFR_ERR_ARG;
+    if (!h->U) return fail(h, IFR_ERR_STATE, "ifr_score_dense: factors not set");
+    if (n == 0) return IFR_OK;
+    if (!user_ids || !out || n < 0 || ld < h->n_items) return fail(h, IFR_ERR_ARG, "ifr_score_dense: null argument or ld < n_items");
+    IFR_HIP(h, hipSetDevice(h->device));
+    int chunk_tiles, n_chunks;
+    pick_chunks(h, n, &chunk_tiles, &n_chunks);
+    const int64_t n_ut = (n + ifr::USERS_PER_BLOCK - 1) / ifr::USERS_PER_BLOCK;
+    const int64_t grid = n_ut * n_chunks;
+    if (grid > 0x7fffffff) return fail(h, IFR_ERR_ARG, "ifr_score_dense: batch too large");
+    ifr::DenseParams p;
+    p.U = h->U; p.V = h->V; p.ibase = h->ibase; p.ubase = h->ubase; p.user_ids = user_ids; p.n = n;
+    p.n_items = (int)h->n_items; p.n_tiles = h->n_tiles; p.chunk_tiles = chunk_tiles; p.n_chunks = n_chunks;
+    p.out = out; p.ld = ld;
+    hipStream_t s = (hipStream_t)stream;
+    if (h->KD == 32) launch_dense<32>(h->has_base, p, (int)grid, s);
+    else if (h->KD == 64) launch_dense<64>(h->has_base, p, (int)grid, s);
+    else launch_dense<128>(h->has_base, p, (int)grid, s);
+    IFR_HIP(h, hipGetLastError());
+    return IFR_OK;
+}
+
+int ifr_auc_dense(ifr_handle h, const int32_t *user_ids, int64_t n, const float *scores, int64_t ld, double *out_auc,
+                  void *stream)
+{
+    if (!h) return IFR_ERR_ARG;
+    if (!h->tr_ptr || h->n_items <= 0) return fail(h, IFR_ERR_STATE, "ifr_auc_dense: factors / truth CSR not set");
+    if (n == 0) return IFR_OK;
+    if (!user_ids || !scores || !out_auc || n < 0 || ld < h->n_items) return fail(h, IFR_ERR_ARG, "ifr_auc_dense: bad argument");
+    if (h->tr_max_row > 8192) return fail(h, IFR_ERR_ARG, "ifr_auc_dense: more than 8192 positives in one row");
+    IFR_HIP(h, hipSetDevice(h->device));
+    int rc = ifr::launch_auc(scores, ld, user_ids, n, (int)h->n_items, h->ex_ptr, h->ex_idx, h->ex_rows, h->tr_ptr,
+                             h->tr_idx, h->tr_rows, out_auc, (hipStream_t)stream);
+    if (rc) return fail(h, IFR_ERR_HIP, "ifr_auc_dense: launch failed");
+    return IFR_OK;
+}
+
+int ifr_rank_full(ifr_handle h, const int32_t *user_ids, int64_t n, const float *scores, int64_t ld, int32_t *out_ids,
+                  int32_t *n_cand, void *stream)
+{
+    if (!h) return IFR_ERR_ARG;
+    if (h->n_items <= 0) return fail(h, IFR_ERR_STATE, "ifr_rank_full: factors not set");
+    if (n == 0) return IFR_OK;
+    if (!user_ids || !scores || !out_ids || !n_cand || n < 0 || ld < h->n_items) return fail(h, IFR_ERR_ARG, "ifr_rank_full: bad argument");
+    IFR_HIP(h, hipSetDevice(h->device));
+    int rc = ifr::launch_rank_full(scores, ld, user_ids, n, (int)h->n_items, h->ex_ptr, h->ex_idx, h->ex_rows, out_ids,
+                                   n_cand, &h->ws_sort, &h->ws_sort_bytes, (hipStream_t)stream);
+    if (rc) return fail(h, rc, "ifr_rank_full: sort failed");
+    return IFR_OK;
+}
+
+int ifr_profile_enable(ifr_handle h, int on)
+{
+    if (!h) return IFR_ERR_ARG;
+    h->prof = on != 0;
+    return IFR_OK;
+}
+
+int ifr_profile_read(ifr_handle h, double *kernel_ms, int64_t *launches, double *pairs_scored)
+{
+    if (!h) return IFR_ERR_ARG;
+    double ms = 0.0;
+    for (auto &e : h->ev_used) {
+        IFR_HIP(h, hipEventSynchronize(e.second));
+        float t = 0.f;
+        IFR_HIP(h, hipEventElapsedTime(&t, e.first, e.second));
+        ms += t;
+        h->ev_free.push_back(e);
+    }
+    if (kernel_ms) *kernel_ms = ms;
+    if (launches) *launches = (int64_t)h->ev_used.size();
+    if (pairs_scored) *pairs_scored = h->prof_pairs;
+    h->ev_used.clear();
+    h->prof_pairs = 0.0;
+    return IFR_OK;
+}
+
+int ifr_factor_chain_order(ifr_handle h, int32_t *perm, int *n)
+{
+    if (!h || !perm || !n) return IFR_ERR_ARG;
+    if (h->KD == 0) return fail(h, IFR_ERR_STATE, "ifr_factor_chain_order: factors not set");
+    // MFMA step 4g+e multiplies k = 8g+e (lanes 0-31) then k = 8g+4+e (lanes 32-63).
+    int t = 0;
+    for (int g = 0; g < h->KD / 8; ++g)
+        for (int e = 0; e < 4; ++e) { perm[t++] = 8 * g + e; perm[t++] = 8 * g + 4 + e; }
+    *n = h->KD;
+    return IFR_OK;
+}
+
+}  // extern "C"

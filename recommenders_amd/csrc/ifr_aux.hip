@@ -1,0 +1,180 @@
+// ifr_aux.hip -- the two consumers of dense score rows: per-user AUC and the full (k = -1)
+// ranking.  Both are HBM-bound passes over [n][n_items] fp32 rows.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <cstring>
+#include <rocprim/device/device_segmented_radix_sort.hpp>
+#include <rocprim/iterator/counting_iterator.hpp>
+#include <rocprim/iterator/transform_iterator.hpp>
+
+namespace ifr {
+
+constexpr int AUC_BLOCK = 256;
+constexpr int AUC_MAX_POS = 8192;
+
+// number of sorted-ascending values strictly greater than s
+__device__ __forceinline__ int count_gt(const float *ps, int n, float s)
+{
+    int lo = 0, hi = n;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (ps[mid] > s) hi = mid; else lo = mid + 1; }
+    return n - lo;
+}
+
+// AUC = #{(p, q): s_p > s_q, p positive, q negative} / (|pos| * |neg|), neg = all - excl - pos.
+// With excl and pos disjoint, wins = W(all) - W(excl) - W(pos), W(S) = sum_{i in S} #{p: s_p > s_i},
+// so no membership test is needed: three coalesced / gathered passes with a binary search each.
+__global__ __launch_bounds__(AUC_BLOCK) void auc_kernel(const float *scores, int64_t ld, const int32_t *user_ids,
+                                                        int n_items, const int64_t *ex_ptr, const int32_t *ex_idx,
+                                                        int64_t ex_rows, const int64_t *tr_ptr, const int32_t *tr_idx,
+                                                        int64_t tr_rows, double *out)
+{
+    __shared__ float ps[AUC_MAX_POS];
+    __shared__ unsigned long long red[AUC_BLOCK / 64];
+    const int64_t i = blockIdx.x;
+    const int u = user_ids[i];
+    const float *row = scores + i * ld;
+    int64_t tb = 0, te = 0, eb = 0, ee = 0;
+    if (u < tr_rows) { tb = tr_ptr[u]; te = tr_ptr[u + 1]; }
+    if (ex_ptr != nullptr && u < ex_rows) { eb = ex_ptr[u]; ee = ex_ptr[u + 1]; }
+    const int n_pos = (int)(te - tb);
+    if (n_pos == 0) {
+        if (threadIdx.x == 0) out[i] = __longlong_as_double(0x7ff8000000000000LL);
+        return;
+    }
+    int np2 = 1;
+    while (np2 < n_pos) np2 <<= 1;
+    for (int q = threadIdx.x; q < np2; q += AUC_BLOCK) ps[q] = q < n_pos ? row[tr_idx[tb + q]] : INFINITY;
+    __syncthreads();
+    // bitonic sort ascending in LDS
+    for (int k = 2; k <= np2; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int q = threadIdx.x; q < np2; q += AUC_BLOCK) {
+                const int x = q ^ j;
+                if (x > q) {
+                    const float a = ps[q], b = ps[x];
+                    const bool up = (q & k) == 0;
+                    if ((a > b) == up) { ps[q] = b; ps[x] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    long long wins = 0;
+    for (int it = threadIdx.x; it < n_items; it += AUC_BLOCK) wins += count_gt(ps, n_pos, row[it]);
+    for (int64_t q = eb + threadIdx.x; q < ee; q += AUC_BLOCK) {
+        const int it = ex_idx[q];
+        if (it >= 0 && it < n_items) wins -= count_gt(ps, n_pos, row[it]);
+    }
+    int n_ex = 0;
+    for (int64_t q = eb + threadIdx.x; q < ee; q += AUC_BLOCK) {
+        const int it = ex_idx[q];
+        n_ex += (it >= 0 && it < n_items) ? 1 : 0;
+    }
+    for (int q = threadIdx.x; q < n_pos; q += AUC_BLOCK) wins -= count_gt(ps, n_pos, ps[q]);
+    long long w = wins;                                       // may be transiently negative per thread
+    int ne = n_ex;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) { w += __shfl_xor(w, off); ne += __shfl_xor(ne, off); }
+    __shared__ int red_ne[AUC_BLOCK / 64];
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = (unsigned long long)w; red_ne[threadIdx.x >> 6] = ne; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        long long tw = 0; int tne = 0;
+        for (int q = 0; q < AUC_BLOCK / 64; ++q) { tw += (long long)red[q]; tne += red_ne[q]; }
+        const double n_neg = (double)n_items - (double)tne - (double)n_pos;
+        out[i] = (double)tw / ((double)n_pos * n_neg);
+    }
+}
+
+int launch_auc(const float *scores, int64_t ld, const int32_t *user_ids, int64_t n, int n_items,
+               const int64_t *ex_ptr, const int32_t *ex_idx, int64_t ex_rows, const int64_t *tr_ptr,
+               const int32_t *tr_idx, int64_t tr_rows, double *out, hipStream_t stream)
+{
+    hipLaunchKernelGGL(auc_kernel, dim3((unsigned)n), dim3(AUC_BLOCK), 0, stream, scores, ld, user_ids, n_items, ex_ptr,
+                       ex_idx, ex_rows, tr_ptr, tr_idx, tr_rows, out);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+// ------------------------------------------------------------------------------------
+// Full ranking: 64-bit keys (descending-score bits, item id) sorted ascending per user row.
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t desc_key(float s)
+{
+    uint32_t b = __float_as_uint(s);
+    b = (b & 0x80000000u) ? ~b : (b | 0x80000000u);   // ascending-orderable
+    return ~b;                                         // descending
+}
+
+__global__ void build_keys_kernel(const float *scores, int64_t ld, int n_items, uint64_t *keys)
+{
+    const int64_t i = blockIdx.y;
+    const int it = blockIdx.x * blockDim.x + threadIdx.x;
+    if (it >= n_items) return;
+    const float s = scores[i * ld + it];
+    keys[i * n_items + it] = ((uint64_t)desc_key(s) << 32) | (uint32_t)it;
+}
+
+__global__ void kill_excluded_kernel(const int32_t *user_ids, int n_items, const int64_t *ex_ptr, const int32_t *ex_idx,
+                                     int64_t ex_rows, uint64_t *keys, int32_t *n_cand)
+{
+    const int64_t i = blockIdx.x;
+    const int u = user_ids[i];
+    int64_t eb = 0, ee = 0;
+    if (ex_ptr != nullptr && u < ex_rows) { eb = ex_ptr[u]; ee = ex_ptr[u + 1]; }
+    int c = 0;
+    for (int64_t q = eb + threadIdx.x; q < ee; q += blockDim.x) {
+        const int it = ex_idx[q];
+        if (it >= 0 && it < n_items) { keys[i * n_items + it] = ~0ull; ++c; }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) c += __shfl_xor(c, off);
+    if (threadIdx.x == 0) n_cand[i] = n_items - c;       // blockDim.x == 64
+}
+
+__global__ void keys_to_ids_kernel(const uint64_t *keys, int n_items, int64_t ld, const int32_t *n_cand, int32_t *out)
+{
+    const int64_t i = blockIdx.y;
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= ld) return;
+    out[i * ld + r] = (r < n_cand[i]) ? (int32_t)(uint32_t)keys[i * n_items + r] : -1;
+}
+
+struct row_offsets {
+    int64_t stride;
+    __host__ __device__ int64_t operator()(int64_t i) const { return i * stride; }
+};
+
+int launch_rank_full(const float *scores, int64_t ld, const int32_t *user_ids, int64_t n, int n_items,
+                     const int64_t *ex_ptr, const int32_t *ex_idx, int64_t ex_rows, int32_t *out_ids, int32_t *n_cand,
+                     void **ws, size_t *ws_bytes, hipStream_t stream)
+{
+    const size_t key_bytes = sizeof(uint64_t) * (size_t)n * n_items;
+    auto offs = rocprim::make_transform_iterator(rocprim::make_counting_iterator<int64_t>(0), row_offsets{n_items});
+    size_t tmp_bytes = 0;
+    uint64_t *null_keys = nullptr;
+    if (rocprim::segmented_radix_sort_keys(nullptr, tmp_bytes, null_keys, null_keys, (unsigned)((size_t)n * n_items),
+                                           (unsigned)n, offs, offs + 1, 0, 64, stream) != hipSuccess)
+        return -3;
+    const size_t need = 2 * key_bytes + tmp_bytes + 512;
+    if (*ws_bytes < need) {
+        if (*ws) (void)hipFree(*ws);
+        *ws = nullptr; *ws_bytes = 0;
+        if (hipMalloc(ws, need) != hipSuccess) return -4;
+        *ws_bytes = need;
+    }
+    uint64_t *k_in = (uint64_t *)*ws;
+    uint64_t *k_out = (uint64_t *)((char *)*ws + key_bytes);
+    void *tmp = (char *)*ws + 2 * key_bytes;
+    dim3 g((n_items + 255) / 256, (unsigned)n);
+    hipLaunchKernelGGL(build_keys_kernel, g, dim3(256), 0, stream, scores, ld, n_items, k_in);
+    hipLaunchKernelGGL(kill_excluded_kernel, dim3((unsigned)n), dim3(64), 0, stream, user_ids, n_items, ex_ptr, ex_idx,
+                       ex_rows, k_in, n_cand);
+    if (rocprim::segmented_radix_sort_keys(tmp, tmp_bytes, k_in, k_out, (unsigned)((size_t)n * n_items), (unsigned)n,
+                                           offs, offs + 1, 0, 64, stream) != hipSuccess)
+        return -3;
+    dim3 g2((unsigned)((ld + 255) / 256), (unsigned)n);
+    hipLaunchKernelGGL(keys_to_ids_kernel, g2, dim3(256), 0, stream, k_out, n_items, ld, n_cand, out_ids);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+}  // namespace ifr

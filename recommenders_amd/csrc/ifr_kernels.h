@@ -1,0 +1,525 @@
+// ifr_kernels.h -- CDNA4 (gfx950) kernels of the scoring + ranking-evaluation path.
+//
+// Layout in HBM (owned by the handle, see ifr_api.hip):
+//   U      [n_users][KD]        fp32, KD = k padded to 32/64/128 with zeros
+//   V      [n_tiles*32 + 32][KD] fp32, zero rows past n_items (one spare tile so the
+//                                prefetch of "tile + 1" never leaves the allocation)
+//   ibase  [n_tiles*32 + 32]    fp32 item-side base (bias), zeros if the model has none
+//   ubase  [n_users]            fp32 user-side base
+//   exclusions as per-user lists of (tile, 32-bit mask) stored in place of the CSR row:
+//          entries of user u live at ex_ptr[u] .. ex_ptr[u] + ex_cnt[u]
+//
+// The fused kernel computes a 32(items) x 32(users) score block per wave with
+// v_mfma_f32_32x32x2_f32: A = item factors read from an LDS tile, B = user factors held in
+// registers for the whole item sweep.  In the accumulator a lane owns ONE user (column
+// lane&31) and 16 item rows, so the per-user running top-K is lane-private: no cross-lane
+// traffic in the select.  Scores never leave the CU.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ifr {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int TILE_I = 32;        // items per LDS tile (one MFMA block)
+constexpr int WAVES = 4;          // waves per workgroup
+constexpr int BLOCK = 256;
+constexpr int USERS_PER_BLOCK = 128;
+constexpr int PEND = 16;          // pending-candidate slots per lane (LDS)
+constexpr int NO_TILE = 0x7fffffff;
+
+struct TopkParams {
+    const float *U, *V, *ibase, *ubase;
+    const int32_t *user_ids;
+    int64_t n;               // users in this batch
+    int n_items;
+    int n_tiles;             // ceil(n_items / 32)
+    int chunk_tiles;         // tiles per item chunk
+    int n_chunks;
+    int K;                   // requested list length (<= KL)
+    const int64_t *ex_ptr;   // may be null
+    const int32_t *ex_cnt;
+    const int32_t *ex_tile;
+    const uint32_t *ex_mask;
+    int64_t ex_rows;
+    float *part_scores;      // [n_slots][n_chunks*2][KL]
+    int32_t *part_ids;
+};
+
+// item row inside a 32x32 accumulator block held by register r of a lane in half h
+__device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+// Sorted insertion into a lane-private descending list.  Strict '>' keeps earlier (smaller
+// item index) entries ahead of later equal scores, which is the canonical tie order because a
+// lane sees its items in ascending index order.
+template <int KL>
+__device__ __forceinline__ void list_insert(float (&ls)[KL], int (&li)[KL], float x, int id)
+{
+#pragma unroll
+    for (int i = KL - 1; i >= 1; --i) {
+        const bool ci = x > ls[i];
+        const bool cim = x > ls[i - 1];
+        li[i] = ci ? (cim ? li[i - 1] : id) : li[i];
+        ls[i] = __builtin_amdgcn_fmed3f(x, ls[i - 1], ls[i]);
+    }
+    li[0] = (x > ls[0]) ? id : li[0];
+    ls[0] = fmaxf(x, ls[0]);
+}
+
+template <int KL>
+__device__ __forceinline__ float list_tau(const float (&ls)[KL], int K)
+{
+    // ls is descending, so the K-th best is the minimum of the first K entries (written as a
+    // min chain: an 'i == K-1' select chain is turned into a scratch-indexed load by hipcc)
+    float t = ls[0];
+#pragma unroll
+    for (int i = 1; i < KL; ++i) t = (i < K) ? fminf(t, ls[i]) : t;
+    return t;
+}
+
+// ------------------------------------------------------------------------------------
+// Fused score + exclusion + per-user top-K over one (user tile, item chunk).
+// grid.x = n_chunks * n_user_tiles, chunk-major so that concurrently resident workgroups
+// stream the same item chunk through L2.
+// ------------------------------------------------------------------------------------
+template <int KD, int KL, bool HAS_BASE>
+__global__ __launch_bounds__(BLOCK, 2) void score_topk_kernel(TopkParams p)
+{
+    constexpr int ROW = KD + 4;                 // padded LDS row (floats); +4 => conflict-free b128 reads
+    constexpr int C4 = KD / 4;                  // float4 chunks per factor row
+    constexpr int STAGE = (TILE_I * C4) / BLOCK; // float4 loads per thread per tile
+    static_assert((TILE_I * C4) % BLOCK == 0, "tile must split evenly");
+    __shared__ __attribute__((aligned(16))) float vt[2][TILE_I][ROW];
+    __shared__ uint2 pend[PEND][BLOCK];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const int n_ut = (int)((p.n + USERS_PER_BLOCK - 1) / USERS_PER_BLOCK);
+    const int chunk = blockIdx.x / n_ut;
+    const int ut = blockIdx.x - chunk * n_ut;
+    const int t0 = chunk * p.chunk_tiles;
+    const int t1 = min(t0 + p.chunk_tiles, p.n_tiles);
+
+    const int64_t slot = (int64_t)ut * USERS_PER_BLOCK + wave * 32 + j;
+    const bool live = slot < p.n;
+    const int uid = p.user_ids[live ? slot : p.n - 1];
+
+    // user factors: lane (j,h) keeps U[uid][8g + 4h + e], g < KD/8, e < 4
+    f32x4 ureg[KD / 8];
+    {
+        const float *up = p.U + (int64_t)uid * KD + 4 * h;
+#pragma unroll
+        for (int g = 0; g < KD / 8; ++g) ureg[g] = *reinterpret_cast<const f32x4 *>(up + 8 * g);
+    }
+    const float ub = HAS_BASE ? p.ubase[uid] : 0.0f;
+
+    // exclusion cursor: first (tile, mask) entry with tile >= t0
+    int64_t ex_cur = 0, ex_end = 0;
+    int nt = NO_TILE;
+    uint32_t nm = 0;
+    if (p.ex_ptr != nullptr && uid < p.ex_rows) {
+        const int64_t b = p.ex_ptr[uid];
+        int lo = 0, hi = p.ex_cnt[uid];
+        ex_end = b + hi;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (p.ex_tile[b + mid] < t0) lo = mid + 1; else hi = mid;
+        }
+        ex_cur = b + lo;
+        if (ex_cur < ex_end) { nt = p.ex_tile[ex_cur]; nm = p.ex_mask[ex_cur]; }
+    }
+
+    float ls[KL];
+    int li[KL];
+#pragma unroll
+    for (int i = 0; i < KL; ++i) { ls[i] = -INFINITY; li[i] = NO_TILE; }
+    float tau = -INFINITY;
+    int cnt = 0;
+
+    // ---- stage tile t0 into buffer 0
+    f32x4 st[STAGE];
+    float st_b = 0.0f;
+    auto stage_load = [&](int t) {
+        const float *src = p.V + (int64_t)t * TILE_I * KD;
+#pragma unroll
+        for (int q = 0; q < STAGE; ++q)
+            st[q] = *reinterpret_cast<const f32x4 *>(src + (int64_t)(tid + q * BLOCK) * 4);
+        if (HAS_BASE && tid < TILE_I) st_b = p.ibase[t * TILE_I + tid];
+    };
+    auto stage_store = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < STAGE; ++q) {
+            const int idx = tid + q * BLOCK;
+            const int row = idx / C4, c4 = idx - row * C4;
+            *reinterpret_cast<f32x4 *>(&vt[buf][row][c4 * 4]) = st[q];
+        }
+        if (HAS_BASE && tid < TILE_I) vt[buf][tid][KD] = st_b;
+    };
+    if (t0 < t1) { stage_load(t0); stage_store(0); }
+    __syncthreads();
+
+    for (int t = t0; t < t1; ++t) {
+        const int buf = (t - t0) & 1;
+        if (t + 1 < t1) stage_load(t + 1);
+
+        // ---- 32 items x 32 users x KD on the matrix core
+        f32x16 acc = {0};
+        const float *arow = &vt[buf][j][4 * h];
+#pragma unroll
+        for (int g = 0; g < KD / 8; ++g) {
+            const f32x4 a4 = *reinterpret_cast<const f32x4 *>(arow + 8 * g);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[0], ureg[g][0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[1], ureg[g][1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[2], ureg[g][2], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[3], ureg[g][3], acc, 0, 0, 0);
+        }
+
+        float s[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            if (HAS_BASE) {
+                const float base = vt[buf][acc_row(r, h)][KD] + ub;   // (ibase + ubase) + dot
+                s[r] = base + acc[r];
+            } else {
+                s[r] = acc[r];
+            }
+        }
+
+        // ---- exclusions (and rows past n_items) become NaN: they never compare '>'
+        uint32_t m = 0;
+        if (nt == t) {
+            m = nm;
+            ++ex_cur;
+            if (ex_cur < ex_end) { nt = p.ex_tile[ex_cur]; nm = p.ex_mask[ex_cur]; } else nt = NO_TILE;
+        }
+        if (t == p.n_tiles - 1) {
+            const int valid = p.n_items - t * TILE_I;       // 1..32
+            if (valid < 32) m |= ~0u << valid;
+        }
+        if (__any(m != 0)) {
+            const uint32_t mm = m >> (4 * h);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int bit = (r & 3) + 8 * (r >> 2);
+                const uint32_t kill = (uint32_t)(-(int32_t)((mm >> bit) & 1u));   // 0 or ~0
+                s[r] = __uint_as_float(__float_as_uint(s[r]) | (kill & 0xFFC00000u));
+            }
+        }
+
+        // ---- threshold filter: one max-reduce per lane, then a wave vote
+        float mx = fmaxf(fmaxf(s[0], s[1]), s[2]);
+#pragma unroll
+        for (int r = 3; r + 1 < 16; r += 2) mx = fmaxf(fmaxf(mx, s[r]), s[r + 1]);
+        mx = fmaxf(mx, s[15]);
+        if (__any(mx > tau)) {
+            uint32_t hits = 0;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) hits |= (s[r] > tau ? 1u : 0u) << r;
+            if (__any(cnt + __popc(hits) > PEND)) {
+                // drain the pending slots into the register lists, raise tau, re-filter
+                for (int q = 0; __any(q < cnt); ++q) {
+                    if (q < cnt) {
+                        const uint2 e = pend[q][tid];
+                        list_insert<KL>(ls, li, __uint_as_float(e.x), (int)e.y);
+                    }
+                }
+                cnt = 0;
+                tau = list_tau<KL>(ls, p.K);
+                hits = 0;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) hits |= (s[r] > tau ? 1u : 0u) << r;
+            }
+            const int item0 = t * TILE_I + 4 * h;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                if (hits & (1u << r)) {
+                    pend[cnt][tid] = make_uint2(__float_as_uint(s[r]), (uint32_t)(item0 + (r & 3) + 8 * (r >> 2)));
+                    ++cnt;
+                }
+            }
+        }
+
+        if (t + 1 < t1) stage_store(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- final drain and write the lane's partial list
+    for (int q = 0; __any(q < cnt); ++q) {
+        if (q < cnt) {
+            const uint2 e = pend[q][tid];
+            list_insert<KL>(ls, li, __uint_as_float(e.x), (int)e.y);
+        }
+    }
+    if (live) {
+        const int64_t base = ((slot * p.n_chunks + chunk) * 2 + h) * KL;
+#pragma unroll
+        for (int i = 0; i < KL; ++i) { p.part_scores[base + i] = ls[i]; p.part_ids[base + i] = li[i]; }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// Merge the 2*n_chunks partial lists of a user into the final top-K (score desc, id asc).
+// One wave per user.  Each entry's final rank = number of entries that beat it, obtained
+// with one binary search per (sorted) partial list.
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ bool beats(float s, int id, float s2, int id2)
+{
+    return (s > s2) || (s == s2 && id < id2);
+}
+
+template <int KL>
+__global__ __launch_bounds__(64) void merge_topk_kernel(const float *part_scores, const int32_t *part_ids,
+                                                        int64_t n, int n_lists, int K,
+                                                        int32_t *out_ids, float *out_scores)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float *es = reinterpret_cast<float *>(smem);
+    int *ei = reinterpret_cast<int *>(smem) + n_lists * KL;
+    const int64_t u = blockIdx.x;
+    const int lane = threadIdx.x;
+    const int E = n_lists * KL;
+    const float *ps = part_scores + u * E;
+    const int32_t *pi = part_ids + u * E;
+    for (int e = lane; e < E; e += 64) { es[e] = ps[e]; ei[e] = pi[e]; }
+    __syncthreads();
+    int n_valid = 0;
+    for (int e = lane; e < E; e += 64) {
+        const float s = es[e];
+        const int id = ei[e];
+        if (id == NO_TILE) continue;          // unfilled slot
+        ++n_valid;
+        int rank = 0;
+        for (int l = 0; l < n_lists; ++l) {
+            const float *lsp = es + l * KL;
+            const int *lip = ei + l * KL;
+            int lo = 0, hi = KL;                // first position that does NOT beat (s,id)
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (beats(lsp[mid], lip[mid], s, id)) lo = mid + 1; else hi = mid;
+            }
+            rank += lo;
+        }
+        if (rank < K) { out_ids[u * K + rank] = id; out_scores[u * K + rank] = s; }
+    }
+    // fewer than K candidates: pad the tail
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) n_valid += __shfl_xor(n_valid, off);
+    for (int r = n_valid + lane; r < K; r += 64) { out_ids[u * K + r] = -1; out_scores[u * K + r] = -INFINITY; }
+}
+
+// ------------------------------------------------------------------------------------
+// Dense score rows out[slot][item] for a batch of users (same fma chain as the fused
+// kernel, operand roles swapped so a lane owns an item column and stores are coalesced).
+// ------------------------------------------------------------------------------------
+struct DenseParams {
+    const float *U, *V, *ibase, *ubase;
+    const int32_t *user_ids;
+    int64_t n;
+    int n_items, n_tiles, chunk_tiles, n_chunks;
+    float *out;
+    int64_t ld;
+};
+
+template <int KD, bool HAS_BASE>
+__global__ __launch_bounds__(BLOCK, 2) void score_dense_kernel(DenseParams p)
+{
+    constexpr int ROW = KD + 4;
+    constexpr int C4 = KD / 4;
+    constexpr int STAGE = (TILE_I * C4) / BLOCK;
+    __shared__ __attribute__((aligned(16))) float vt[2][TILE_I][ROW];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const int n_ut = (int)((p.n + USERS_PER_BLOCK - 1) / USERS_PER_BLOCK);
+    const int chunk = blockIdx.x / n_ut;
+    const int ut = blockIdx.x - chunk * n_ut;
+    const int t0 = chunk * p.chunk_tiles;
+    const int t1 = min(t0 + p.chunk_tiles, p.n_tiles);
+
+    const int64_t slot0 = (int64_t)ut * USERS_PER_BLOCK + wave * 32;
+    const int64_t slot = slot0 + j;
+    const int uid = p.user_ids[slot < p.n ? slot : p.n - 1];
+    f32x4 ureg[KD / 8];
+    {
+        const float *up = p.U + (int64_t)uid * KD + 4 * h;
+#pragma unroll
+        for (int g = 0; g < KD / 8; ++g) ureg[g] = *reinterpret_cast<const f32x4 *>(up + 8 * g);
+    }
+    float ubr[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int64_t sl = slot0 + acc_row(r, h);
+        ubr[r] = HAS_BASE ? p.ubase[p.user_ids[sl < p.n ? sl : p.n - 1]] : 0.0f;
+    }
+
+    f32x4 st[STAGE];
+    float st_b = 0.0f;
+    auto stage_load = [&](int t) {
+        const float *src = p.V + (int64_t)t * TILE_I * KD;
+#pragma unroll
+        for (int q = 0; q < STAGE; ++q)
+            st[q] = *reinterpret_cast<const f32x4 *>(src + (int64_t)(tid + q * BLOCK) * 4);
+        if (HAS_BASE && tid < TILE_I) st_b = p.ibase[t * TILE_I + tid];
+    };
+    auto stage_store = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < STAGE; ++q) {
+            const int idx = tid + q * BLOCK;
+            const int row = idx / C4, c4 = idx - row * C4;
+            *reinterpret_cast<f32x4 *>(&vt[buf][row][c4 * 4]) = st[q];
+        }
+        if (HAS_BASE && tid < TILE_I) vt[buf][tid][KD] = st_b;
+    };
+    if (t0 < t1) { stage_load(t0); stage_store(0); }
+    __syncthreads();
+
+    for (int t = t0; t < t1; ++t) {
+        const int buf = (t - t0) & 1;
+        if (t + 1 < t1) stage_load(t + 1);
+        f32x16 acc = {0};
+        const float *vrow = &vt[buf][j][4 * h];
+#pragma unroll
+        for (int g = 0; g < KD / 8; ++g) {
+            const f32x4 b4 = *reinterpret_cast<const f32x4 *>(vrow + 8 * g);
+            // A = user fragment, B = item fragment: D[user row][item col]; the products and
+            // the chain order are the ones of the fused kernel (item*user, k0 then k1).
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ureg[g][0], b4[0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ureg[g][1], b4[1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ureg[g][2], b4[2], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ureg[g][3], b4[3], acc, 0, 0, 0);
+        }
+        const int item = t * TILE_I + j;
+        const float ib = HAS_BASE ? vt[buf][j][KD] : 0.0f;
+        if (item < p.n_items) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t sl = slot0 + acc_row(r, h);
+                if (sl < p.n) {
+                    const float sc = HAS_BASE ? ((ib + ubr[r]) + acc[r]) : acc[r];
+                    p.out[sl * p.ld + item] = sc;
+                }
+            }
+        }
+        if (t + 1 < t1) stage_store(buf ^ 1);
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// Exclusion CSR -> per-user (tile, mask) lists, written in place of the CSR row.
+// ------------------------------------------------------------------------------------
+__global__ void encode_exclusions_kernel(const int64_t *indptr, const int32_t *indices, int64_t n_rows,
+                                         int n_items, int32_t *ex_cnt, int32_t *ex_tile, uint32_t *ex_mask)
+{
+    const int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= n_rows) return;
+    const int64_t b = indptr[u], e = indptr[u + 1];
+    int tile = -1, c = 0;
+    uint32_t mask = 0;
+    for (int64_t i = b; i < e; ++i) {
+        const int it = indices[i];
+        if (it < 0 || it >= n_items) continue;
+        const int T = it >> 5;
+        if (T != tile) {
+            if (tile >= 0) { ex_tile[b + c] = tile; ex_mask[b + c] = mask; ++c; }
+            tile = T; mask = 0;
+        }
+        mask |= 1u << (it & 31);
+    }
+    if (tile >= 0) { ex_tile[b + c] = tile; ex_mask[b + c] = mask; ++c; }
+    ex_cnt[u] = c;
+}
+
+// ------------------------------------------------------------------------------------
+// NDCG@k / Recall@k / Precision@k per user from top-K ids and the truth CSR.
+// ------------------------------------------------------------------------------------
+constexpr int MAX_KS = 8;
+struct MetricParams {
+    const int32_t *user_ids;
+    int64_t n;
+    const int32_t *topk;
+    int K;
+    int ks[MAX_KS];
+    int n_k;
+    const int64_t *tr_ptr;
+    const int32_t *tr_idx;
+    int64_t tr_rows;
+    const double *discount;      // [IFR_MAX_TOPK] 1/log2(i+2)
+    double *per_user;            // [n][3*n_k]
+    int32_t *evaluated;
+    double *block_sums;          // [gridDim.x][3*n_k + 1]
+};
+
+__global__ __launch_bounds__(BLOCK) void metrics_kernel(MetricParams p)
+{
+    __shared__ double red[BLOCK / 64][3 * MAX_KS + 1];
+    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    const int ncol = 3 * p.n_k;
+    double vals[3 * MAX_KS + 1];
+#pragma unroll
+    for (int c = 0; c < 3 * MAX_KS + 1; ++c) vals[c] = 0.0;
+    if (i < p.n) {
+        const int u = p.user_ids[i];
+        int64_t b = 0, e = 0;
+        if (u < p.tr_rows) { b = p.tr_ptr[u]; e = p.tr_ptr[u + 1]; }
+        const int n_pos = (int)(e - b);
+        if (n_pos == 0) {
+            p.evaluated[i] = 0;
+            for (int c = 0; c < ncol; ++c) p.per_user[i * ncol + c] = __longlong_as_double(0x7ff8000000000000LL);
+        } else {
+            p.evaluated[i] = 1;
+            // hit flags of the K ranked ids
+            uint32_t hit = 0;
+            for (int r = 0; r < p.K; ++r) {
+                const int id = p.topk[i * p.K + r];
+                int64_t lo = b, hi = e;
+                while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (p.tr_idx[mid] < id) lo = mid + 1; else hi = mid; }
+                if (id >= 0 && lo < e && p.tr_idx[lo] == id) hit |= 1u << r;
+            }
+            for (int q = 0; q < p.n_k; ++q) {
+                const int k = p.ks[q];
+                double dcg = 0.0, idcg = 0.0;
+                int tp = 0;
+                for (int r = 0; r < k; ++r) {
+                    if (hit & (1u << r)) { dcg += p.discount[r]; ++tp; }
+                    if (r < n_pos) idcg += p.discount[r];
+                }
+                const double nd = dcg / idcg, rc = (double)tp / (double)n_pos, pr = (double)tp / (double)k;
+                p.per_user[i * ncol + 3 * q + 0] = nd;
+                p.per_user[i * ncol + 3 * q + 1] = rc;
+                p.per_user[i * ncol + 3 * q + 2] = pr;
+                vals[3 * q + 0] = nd; vals[3 * q + 1] = rc; vals[3 * q + 2] = pr;
+            }
+            vals[ncol] = 1.0;
+        }
+    }
+    // deterministic block reduction: shuffle tree inside a wave, fixed order across waves
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int c = 0; c <= ncol; ++c) {
+        double v = vals[c];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+        if (lane == 0) red[wave][c] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x <= ncol) {
+        double v = 0.0;
+        for (int w = 0; w < BLOCK / 64; ++w) v += red[w][threadIdx.x];
+        p.block_sums[(int64_t)blockIdx.x * (ncol + 1) + threadIdx.x] = v;
+    }
+}
+
+__global__ void reduce_sums_kernel(const double *block_sums, int n_blocks, int ncol1, double *out)
+{
+    const int c = threadIdx.x;
+    if (c >= ncol1) return;
+    double v = 0.0;
+    for (int b = 0; b < n_blocks; ++b) v += block_sums[(int64_t)b * ncol1 + c];
+    out[c] = v;
+}
+
+}  // namespace ifr

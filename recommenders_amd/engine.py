@@ -1,0 +1,187 @@
+"""HipScorer: the batched engine behind the reference-shaped facade.
+
+A thin, allocation-owning wrapper over the C ABI (include/ifr.h).  PyTorch is used only
+for device buffers and the current HIP stream; all compute happens in libifr.so.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+
+
+class IfrError(RuntimeError):
+    """A non-zero status from libifr.so (status -> RuntimeError)."""
+
+
+def _torch():
+    import torch
+    return torch
+
+
+def _host_ptr(a):
+    return ctypes.c_void_p(a.ctypes.data)
+
+
+class HipScorer:
+    """Device-resident model + CSR data and the batched rank / metric entry points."""
+
+    def __init__(self, device=0):
+        torch = _torch()
+        if not torch.cuda.is_available():
+            raise IfrError("HipScorer needs a GPU (torch.cuda.is_available() is False); there is no CPU fallback")
+        self._lib = _lib.load()
+        self.device = torch.device("cuda", int(device) if not isinstance(device, torch.device) else device.index or 0)
+        h = ctypes.c_void_p()
+        rc = self._lib.ifr_create(ctypes.byref(h), self.device.index)
+        if rc != 0:
+            raise IfrError(f"ifr_create failed with status {rc}")
+        self._h = h
+        self.n_users = self.n_items = self.k = 0
+        self.has_exclusions = False
+        self.has_truth = False
+
+    # ------------------------------------------------------------------ plumbing
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.ifr_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != 0:
+            msg = self._lib.ifr_last_error(self._h)
+            raise IfrError(f"libifr status {rc}: {msg.decode() if msg else ''}")
+
+    def _stream(self):
+        return ctypes.c_void_p(_torch().cuda.current_stream(self.device).cuda_stream)
+
+    def _any_ptr(self, x, dtype):
+        """(pointer, keep-alive) for a NumPy array or torch tensor of the given dtype."""
+        torch = _torch()
+        if x is None:
+            return ctypes.c_void_p(0), None
+        if isinstance(x, torch.Tensor):
+            t = x.contiguous()
+            want = {np.float32: torch.float32, np.int32: torch.int32, np.int64: torch.int64}[dtype]
+            if t.dtype != want:
+                t = t.to(want)
+            return ctypes.c_void_p(t.data_ptr()), t
+        a = np.ascontiguousarray(x, dtype=dtype)
+        return _host_ptr(a), a
+
+    def _dev_i32(self, x):
+        torch = _torch()
+        if isinstance(x, torch.Tensor):
+            return x.to(device=self.device, dtype=torch.int32).contiguous()
+        return torch.from_numpy(np.ascontiguousarray(x, dtype=np.int32)).to(self.device)
+
+    def set_option(self, name, value):
+        self._check(self._lib.ifr_set_option(self._h, name.encode(), int(value)))
+
+    # ------------------------------------------------------------------ data
+    def set_factors(self, U, V, ubase=None, ibase=None):
+        n_users, k = U.shape
+        n_items, k2 = V.shape
+        if k != k2:
+            raise ValueError("U and V must have the same number of factors")
+        pu, ku = self._any_ptr(U, np.float32)
+        pv, kv = self._any_ptr(V, np.float32)
+        pub, kub = self._any_ptr(ubase, np.float32)
+        pib, kib = self._any_ptr(ibase, np.float32)
+        self._check(self._lib.ifr_set_factors(self._h, pu, n_users, pv, n_items, k, pub, pib))
+        self.n_users, self.n_items, self.k = int(n_users), int(n_items), int(k)
+        del ku, kv, kub, kib
+
+    def set_exclusion_csr(self, indptr, indices):
+        pp, kp = self._any_ptr(indptr, np.int64)
+        pi, ki = self._any_ptr(indices, np.int32)
+        n_rows = len(indptr) - 1
+        self._check(self._lib.ifr_set_exclusion_csr(self._h, pp, pi, n_rows, len(indices)))
+        self.has_exclusions = n_rows > 0
+        del kp, ki
+
+    def set_truth_csr(self, indptr, indices):
+        pp, kp = self._any_ptr(indptr, np.int64)
+        pi, ki = self._any_ptr(indices, np.int32)
+        n_rows = len(indptr) - 1
+        self._check(self._lib.ifr_set_truth_csr(self._h, pp, pi, n_rows, len(indices)))
+        self.has_truth = n_rows > 0
+        del kp, ki
+
+    # ------------------------------------------------------------------ compute
+    def rank_topk(self, user_ids, K, out_ids=None, out_scores=None):
+        """Top-K (ids int32 [n,K], scores fp32 [n,K]) for the listed users."""
+        torch = _torch()
+        u = self._dev_i32(user_ids)
+        n = u.numel()
+        if out_ids is None:
+            out_ids = torch.empty((n, K), dtype=torch.int32, device=self.device)
+        if out_scores is None:
+            out_scores = torch.empty((n, K), dtype=torch.float32, device=self.device)
+        self._check(self._lib.ifr_rank_topk(self._h, u.data_ptr(), n, int(K), out_ids.data_ptr(),
+                                            out_scores.data_ptr(), self._stream()))
+        return out_ids, out_scores
+
+    def eval_topk_metrics(self, user_ids, topk_ids, ks):
+        """(per_user fp64 [n, 3*len(ks)] = ndcg/recall/precision per cut-off, evaluated int32 [n],
+        sums fp64 [3*len(ks)+1])."""
+        torch = _torch()
+        u = self._dev_i32(user_ids)
+        n = u.numel()
+        ks_arr = (ctypes.c_int32 * len(ks))(*[int(k) for k in ks])
+        per_user = torch.empty((n, 3 * len(ks)), dtype=torch.float64, device=self.device)
+        evaluated = torch.empty((n,), dtype=torch.int32, device=self.device)
+        sums = torch.empty((3 * len(ks) + 1,), dtype=torch.float64, device=self.device)
+        self._check(self._lib.ifr_eval_topk_metrics(
+            self._h, u.data_ptr(), n, topk_ids.data_ptr(), int(topk_ids.shape[1]), ks_arr, len(ks),
+            per_user.data_ptr(), evaluated.data_ptr(), sums.data_ptr(), self._stream()))
+        return per_user, evaluated, sums
+
+    def score_dense(self, user_ids, out=None):
+        torch = _torch()
+        u = self._dev_i32(user_ids)
+        n = u.numel()
+        if out is None:
+            out = torch.empty((n, self.n_items), dtype=torch.float32, device=self.device)
+        self._check(self._lib.ifr_score_dense(self._h, u.data_ptr(), n, out.data_ptr(), out.stride(0), self._stream()))
+        return out
+
+    def auc_dense(self, user_ids, scores):
+        torch = _torch()
+        u = self._dev_i32(user_ids)
+        out = torch.empty((u.numel(),), dtype=torch.float64, device=self.device)
+        self._check(self._lib.ifr_auc_dense(self._h, u.data_ptr(), u.numel(), scores.data_ptr(), scores.stride(0),
+                                            out.data_ptr(), self._stream()))
+        return out
+
+    def rank_full(self, user_ids, scores):
+        """Full canonical ranking of dense rows: (ids int32 [n, ld] padded with -1, n_cand int32 [n])."""
+        torch = _torch()
+        u = self._dev_i32(user_ids)
+        n = u.numel()
+        ids = torch.empty((n, scores.stride(0)), dtype=torch.int32, device=self.device)
+        n_cand = torch.empty((n,), dtype=torch.int32, device=self.device)
+        self._check(self._lib.ifr_rank_full(self._h, u.data_ptr(), n, scores.data_ptr(), scores.stride(0),
+                                            ids.data_ptr(), n_cand.data_ptr(), self._stream()))
+        return ids, n_cand
+
+    # ------------------------------------------------------------------ introspection
+    def chain_order(self):
+        perm = (ctypes.c_int32 * 128)()
+        n = ctypes.c_int(0)
+        self._check(self._lib.ifr_factor_chain_order(self._h, perm, ctypes.byref(n)))
+        return np.asarray(perm[: n.value], dtype=np.int32)
+
+    def profile_enable(self, on=True):
+        self._check(self._lib.ifr_profile_enable(self._h, int(bool(on))))
+
+    def profile_read(self):
+        ms, launches, pairs = ctypes.c_double(0), ctypes.c_int64(0), ctypes.c_double(0)
+        self._check(self._lib.ifr_profile_read(self._h, ctypes.byref(ms), ctypes.byref(launches), ctypes.byref(pairs)))
+        return ms.value, launches.value, pairs.value

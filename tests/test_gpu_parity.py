@@ -1,0 +1,242 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle.
+
+Bars (BASELINE.json north_star): top-K ids bit-exact, fp32 scores within 1e-5 relative
+(here: bit-for-bit against the oracle run in the kernel's documented fma-chain order, and
+within 1e-5 of the k-ascending / BLAS-order scores), metrics within 1e-6.
+"""
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch
+
+
+def _workload(seed, n_users, n_items, k, bias, mean=40):
+    from recommenders_amd import synth
+    rng = np.random.default_rng(seed)
+    U, V, ub, ib = synth.factor_model(rng, n_users, n_items, k, bias)
+    tr_ptr, tr_idx, te_ptr, te_idx = synth.interactions(rng, n_users, n_items, mean, lo=0)
+    return dict(U=U, V=V, ubase=ub, ibase=ib, excl_ptr=tr_ptr, excl_idx=tr_idx, truth_ptr=te_ptr, truth_idx=te_idx,
+                n_users=n_users, n_items=n_items, k=k)
+
+
+def _scorer(w, excl=True, truth=True):
+    from recommenders_amd import HipScorer
+    sc = HipScorer(0)
+    sc.set_factors(w["U"], w["V"], w["ubase"], w["ibase"])
+    if excl:
+        sc.set_exclusion_csr(w["excl_ptr"], w["excl_idx"])
+    if truth:
+        sc.set_truth_csr(w["truth_ptr"], w["truth_idx"])
+    return sc
+
+
+def _oracle(w, users, ks, kmax, kperm, want_auc=False):
+    kp = None if kperm is None else kperm[kperm < w["k"]]
+    return orc.c_ranking_eval_factor(w["U"], w["V"], w["ibase"], w["ubase"], users, w["excl_ptr"], w["excl_idx"],
+                                     w["truth_ptr"], w["truth_idx"], ks, want_auc, kmax, kperm=kp, n_threads=8)
+
+
+@pytest.mark.parametrize("k,bias,K", [(128, False, 10), (50, True, 10), (10, True, 5), (128, True, 20), (64, False, 32)])
+def test_topk_bit_exact_vs_oracle(torch, k, bias, K):
+    w = _workload(1000 + k + K, 777, 3001, k, bias)
+    sc = _scorer(w)
+    users = np.arange(w["n_users"], dtype=np.int32)
+    ids, scores = sc.rank_topk(users, K)
+    ids, scores = ids.cpu().numpy(), scores.cpu().numpy()
+    o_ids, o_sc, _, _ = _oracle(w, users, [K], K, sc.chain_order())
+    np.testing.assert_array_equal(ids, o_ids)
+    np.testing.assert_array_equal(scores, o_sc)            # bit-for-bit in the documented chain order
+    # and within 1e-5 (relative to |u|.|v|) of the k-ascending order the reference's BLAS may use
+    r_ids, r_sc, _, _ = _oracle(w, users, [K], K, None)
+    scale = np.linalg.norm(w["U"], axis=1).max() * np.linalg.norm(w["V"], axis=1).max()
+    same = ids == r_ids
+    assert same.mean() > 0.999
+    assert np.abs(scores[same] - r_sc[same]).max() <= 1e-5 * scale
+
+
+def test_chunking_does_not_change_results(torch):
+    w = _workload(5, 300, 5000, 128, True)
+    sc = _scorer(w)
+    users = np.arange(w["n_users"], dtype=np.int32)
+    ref = None
+    for chunks in (1, 3, 9):
+        sc.set_option("chunks", chunks)
+        ids, scores = sc.rank_topk(users, 10)
+        got = (ids.cpu().numpy(), scores.cpu().numpy())
+        if ref is None:
+            ref = got
+        np.testing.assert_array_equal(got[0], ref[0])
+        np.testing.assert_array_equal(got[1], ref[1])
+
+
+def test_user_subset_order_and_ragged_batch(torch):
+    w = _workload(6, 500, 2000, 64, False)
+    sc = _scorer(w)
+    users = np.random.default_rng(0).permutation(w["n_users"])[:131].astype(np.int32)   # not a multiple of 128
+    ids, scores = sc.rank_topk(users, 10)
+    o_ids, o_sc, _, _ = _oracle(w, users, [10], 10, sc.chain_order())
+    np.testing.assert_array_equal(ids.cpu().numpy(), o_ids)
+    np.testing.assert_array_equal(scores.cpu().numpy(), o_sc)
+    one = sc.rank_topk(users[:1], 10)[0].cpu().numpy()
+    np.testing.assert_array_equal(one, o_ids[:1])
+
+
+def test_ties_break_by_item_index(torch):
+    # constant factors: every score equal -> the canonical order is ascending item index
+    n_users, n_items, k = 130, 1000, 32
+    w = dict(U=np.ones((n_users, k), np.float32), V=np.ones((n_items, k), np.float32), ubase=None, ibase=None,
+             excl_ptr=np.arange(n_users + 1, dtype=np.int64) * 2,
+             excl_idx=np.tile(np.array([0, 3], np.int32), n_users),
+             truth_ptr=np.zeros(n_users + 1, np.int64), truth_idx=np.zeros(0, np.int32), n_users=n_users,
+             n_items=n_items, k=k)
+    sc = _scorer(w, truth=False)
+    sc.set_option("chunks", 4)
+    ids, scores = sc.rank_topk(np.arange(n_users, dtype=np.int32), 10)
+    expect = np.array([1, 2, 4, 5, 6, 7, 8, 9, 10, 11], np.int32)
+    np.testing.assert_array_equal(ids.cpu().numpy(), np.tile(expect, (n_users, 1)))
+    assert (scores.cpu().numpy() == 32.0).all()
+
+
+def test_fewer_candidates_than_k(torch):
+    n_users, n_items, k = 5, 40, 16
+    rng = np.random.default_rng(3)
+    excl = [np.arange(40), np.arange(35), np.zeros(0, int), np.arange(5, 40), np.arange(1, 40)]
+    ptr = np.cumsum([0] + [len(e) for e in excl]).astype(np.int64)
+    w = dict(U=rng.normal(size=(n_users, k)).astype(np.float32), V=rng.normal(size=(n_items, k)).astype(np.float32),
+             ubase=None, ibase=None, excl_ptr=ptr, excl_idx=np.concatenate(excl).astype(np.int32),
+             truth_ptr=np.zeros(n_users + 1, np.int64), truth_idx=np.zeros(0, np.int32), n_users=n_users,
+             n_items=n_items, k=k)
+    sc = _scorer(w, truth=False)
+    users = np.arange(n_users, dtype=np.int32)
+    ids, scores = sc.rank_topk(users, 10)
+    o_ids, o_sc, _, _ = _oracle(w, users, [10], 10, sc.chain_order())
+    np.testing.assert_array_equal(ids.cpu().numpy(), o_ids)
+    np.testing.assert_array_equal(scores.cpu().numpy(), o_sc)
+    assert (ids.cpu().numpy()[0] == -1).all() and (ids.cpu().numpy()[4] == np.r_[0, [-1] * 9]).all()
+
+
+def test_metrics_vs_oracle(torch):
+    w = _workload(8, 1000, 2500, 128, False)
+    sc = _scorer(w)
+    users = np.arange(w["n_users"], dtype=np.int32)
+    ks = [10, 5, 20]
+    ids, _ = sc.rank_topk(users, 20)
+    per_user, evaluated, sums = sc.eval_topk_metrics(users, ids, ks)
+    per_user, evaluated, sums = per_user.cpu().numpy(), evaluated.cpu().numpy(), sums.cpu().numpy()
+    _, _, o_met, o_ev = _oracle(w, users, ks, 20, sc.chain_order())
+    np.testing.assert_array_equal(evaluated, o_ev)
+    assert 0 < evaluated.sum() < len(users) or evaluated.all()
+    ev = evaluated.astype(bool)
+    np.testing.assert_allclose(per_user[ev], o_met[ev][:, :9], rtol=0, atol=1e-12)
+    assert np.isnan(per_user[~ev]).all()
+    np.testing.assert_allclose(sums[:9], o_met[ev][:, :9].sum(0), rtol=1e-12)
+    assert sums[9] == ev.sum()
+    # aggregate (mean over evaluated users, base_method.py:302-303) within 1e-6
+    np.testing.assert_allclose(sums[:9] / sums[9], o_met[ev][:, :9].mean(0), atol=1e-6, rtol=0)
+
+
+def test_dense_scores_match_fused_and_auc(torch):
+    w = _workload(9, 260, 1500, 50, True)
+    sc = _scorer(w)
+    users = np.arange(w["n_users"], dtype=np.int32)
+    dense = sc.score_dense(users)
+    ids, scores = sc.rank_topk(users, 10)
+    gathered = torch.gather(dense, 1, ids.long().clamp(min=0))
+    assert torch.equal(gathered, scores)
+    # dense rows bit-for-bit equal to the oracle in chain order
+    perm = sc.chain_order()
+    perm = perm[perm < w["k"]]
+    for u in (0, 17, 259):
+        ref = orc.c_score_factor(w["U"][u], w["V"], w["ibase"], float(w["ubase"][u]), perm)
+        np.testing.assert_array_equal(dense[u].cpu().numpy(), ref)
+    auc = sc.auc_dense(users, dense).cpu().numpy()
+    _, _, o_met, o_ev = _oracle(w, users, [10], 10, sc.chain_order(), want_auc=True)
+    ev = o_ev.astype(bool)
+    np.testing.assert_allclose(auc[ev], o_met[ev][:, 3], rtol=0, atol=1e-12)
+    assert np.isnan(auc[~ev]).all()
+
+
+def test_rank_full_vs_oracle(torch):
+    w = _workload(10, 70, 900, 32, True)
+    sc = _scorer(w)
+    users = np.arange(w["n_users"], dtype=np.int32)
+    dense = sc.score_dense(users)
+    ids, n_cand = sc.rank_full(users, dense)
+    ids, n_cand, dn = ids.cpu().numpy(), n_cand.cpu().numpy(), dense.cpu().numpy()
+    for u in range(w["n_users"]):
+        ex = w["excl_idx"][w["excl_ptr"][u]: w["excl_ptr"][u + 1]]
+        cand = np.setdiff1d(np.arange(w["n_items"]), ex)
+        expect = orc.canonical_rank(cand, dn[u][cand])
+        assert n_cand[u] == len(cand)
+        np.testing.assert_array_equal(ids[u, : len(cand)], expect)
+        assert (ids[u, len(cand):] == -1).all()
+
+
+@pytest.mark.parametrize("model", ["bpr", "mf", "wmf"])
+def test_golden_reference_fixture(torch, toy, model):
+    """Per-user NDCG/Recall/Precision@K from the HIP path against the values the reference
+    itself produced (tests/golden/toy_all_models.npz)."""
+    from test_oracle import _csr
+    d = toy
+    nu, ni = int(d["num_users"]), int(d["num_items"])
+    thr = float(d["rating_threshold"])
+    train, test, val = _csr(d, "train"), _csr(d, "test"), _csr(d, "val")
+    excl_ptr, excl_idx, tr_ptr, tr_idx = [0], [], [0], []
+    for u in range(nu):
+        pos = orc.pos_items(test, u, thr)
+        pos = pos[pos < ni]
+        ex = np.union1d(orc.pos_items(train, u, thr), orc.pos_items(val, u, thr))
+        ex = np.setdiff1d(ex[ex < ni], pos)
+        excl_idx += ex.tolist(); excl_ptr.append(len(excl_idx))
+        tr_idx += pos.tolist(); tr_ptr.append(len(tr_idx))
+    if model == "bpr":
+        U, V, ub, ib = d["bpr_U"], d["bpr_V"], None, d["bpr_Bi"]
+    elif model == "mf":
+        U, V, ub, ib = d["mf_U"], d["mf_V"], d["mf_Bu"], (np.float32(d["mf_mu"]) + d["mf_Bi"]).astype(np.float32)
+    else:
+        U, V, ub, ib = d["wmf_U"], d["wmf_V"], None, None
+    from recommenders_amd import HipScorer
+    sc = HipScorer(0)
+    sc.set_factors(U, V, ub, ib)
+    sc.set_exclusion_csr(np.asarray(excl_ptr, np.int64), np.asarray(excl_idx, np.int32))
+    sc.set_truth_csr(np.asarray(tr_ptr, np.int64), np.asarray(tr_idx, np.int32))
+    users = d[f"{model}__users"]
+    ids, scores = sc.rank_topk(users, 20)
+    per_user, evaluated, sums = sc.eval_topk_metrics(users, ids, [10, 5, 20])
+    per_user = per_user.cpu().numpy()
+    assert evaluated.cpu().numpy().all()
+    names = [str(x) for x in d["metric_names"]]
+    col = {"ndcg@10": 0, "recall@10": 1, "precision@10": 2, "ndcg@5": 3, "recall@20": 7}
+    ref = d[f"{model}__per_user"]
+    ref_head, ref_hs = d[f"{model}__ranked_head"], d[f"{model}__ranked_head_scores"]
+    ids = ids.cpu().numpy()
+    # the reference's head (top-20) wherever its own scores are separated by > 1e-5 relative
+    gaps = np.abs(np.diff(ref_hs, axis=1))
+    tie_free = (gaps > 1e-5 * np.maximum(1e-3, np.abs(ref_hs[:, :-1]))).all(axis=1)
+    assert tie_free.mean() > 0.8
+    np.testing.assert_array_equal(ids[tie_free][:, :19], ref_head[tie_free][:, :19])
+    # fp32 scores within 1e-5 relative of the reference's
+    s = scores.cpu().numpy()[tie_free][:, :19]
+    r = ref_hs[tie_free][:, :19]
+    assert np.abs(s - r).max() <= 1e-5 * max(1.0, np.abs(r).max())
+    for j, n in enumerate(names):
+        if n in col:
+            np.testing.assert_allclose(per_user[tie_free][:, col[n]], ref[tie_free][:, j], atol=1e-6, rtol=0)
+            # aggregate within 1e-6 of the reference's mean over the same users
+            assert abs(per_user[tie_free][:, col[n]].mean() - ref[tie_free][:, j].mean()) < 1e-6
+    # AUC through the dense path
+    dense = sc.score_dense(users)
+    auc = sc.auc_dense(users, dense).cpu().numpy()
+    j = names.index("auc@-1")
+    assert np.abs(auc - ref[:, j]).max() < 1e-4          # a near-tie may flip single pairs
+    assert abs(auc.mean() - ref[:, j].mean()) < 1e-6
