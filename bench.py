@@ -1,0 +1,173 @@
+"""bench.py -- users ranked/sec (full-catalogue top-10 + NDCG/Recall) on N MI355X.
+
+Contract (see the task statement): `python bench.py --gpus N --steps K --warmup W`; for
+N > 1 the driver launches it under torch.distributed.run, one rank per GPU.  Rank 0 prints
+ONE JSON line.
+
+Workload at N = 1 (and per rank for N > 1, weak scaling): BASELINE.json configs[1],
+"WMF k=128 on MovieLens-20M shape" = 138,493 users x 26,744 items, ~20 M interactions,
+synthetic (recommenders_amd/synth.py).  One step = one pass of the hot path over all of the
+rank's users: fused score + exclusion + top-10 (ifr_rank_topk), NDCG@10 / Recall@10 /
+Precision@10 (ifr_eval_topk_metrics), the all-reduce of the metric sums (N > 1) and the
+D2H copy of the top-10 lists.  Model and CSR data are resident in HBM before timing starts.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+TOPK = 10
+
+
+def cpu_baseline(w, n_sample, chain):
+    """The oracle's C port of the per-user reference loop (oracle/ifr_oracle.c), timed on this
+    box's host cores over a bounded user sample of the same workload."""
+    from oracle import oracle as orc
+    threads = min(16, os.cpu_count() or 1)
+    users = np.arange(n_sample, dtype=np.int32)
+    kp = chain[chain < w["k"]]
+    t = time.perf_counter()
+    ids, sc, met, ev = orc.c_ranking_eval_factor(
+        w["U"], w["V"], w["ibase"], w["ubase"], users, w["excl_ptr"], w["excl_idx"], w["truth_ptr"], w["truth_idx"],
+        [TOPK], False, TOPK, kperm=kp, n_threads=threads)
+    dt = time.perf_counter() - t
+    return dict(value=n_sample / dt, unit="users/s", cores=threads, kind="port",
+                sample=f"{n_sample} users x {w['n_items']} items of the same workload, "
+                       f"oracle/ifr_oracle.c orc_ranking_eval_factor, {dt:.1f} s"), ids, met, ev
+
+
+def cpu_strong(w, n_sample):
+    """Informational: batched sgemm + argpartition on all host threads."""
+    t = time.perf_counter()
+    done = 0
+    for b in range(0, n_sample, 1024):
+        us = np.arange(b, min(b + 1024, n_sample))
+        S = w["U"][us] @ w["V"].T
+        for r, u in enumerate(us):
+            S[r, w["excl_idx"][w["excl_ptr"][u]: w["excl_ptr"][u + 1]]] = -np.inf
+        part = np.argpartition(-S, TOPK, axis=1)[:, :TOPK]
+        np.take_along_axis(S, part, 1).argsort(1)
+        done += len(us)
+    dt = time.perf_counter() - t
+    return dict(value=done / dt, unit="users/s", kind="numpy sgemm+argpartition", sample=f"{done} users, {dt:.1f} s")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="c2_wmf_ml20m")
+    ap.add_argument("--users", type=int, default=None, help="override users per rank (debug only)")
+    ap.add_argument("--items", type=int, default=None, help="override catalogue size (debug only)")
+    ap.add_argument("--cpu-sample", type=int, default=4096)
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from recommenders_amd import HipScorer, synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+
+    # each rank owns one user shard of the configured size (weak scaling); item factors replicated
+    w = synth.make(args.config, n_users=args.users, n_items=args.items,
+                   seed=synth.CONFIGS[args.config][4] + 1000 * rank)
+    sc = HipScorer(local)
+    sc.set_factors(w["U"], w["V"], w["ubase"], w["ibase"])
+    sc.set_exclusion_csr(w["excl_ptr"], w["excl_idx"])
+    sc.set_truth_csr(w["truth_ptr"], w["truth_idx"])
+    n = w["n_users"]
+    users = torch.arange(n, dtype=torch.int32, device=dev)
+    ids = torch.empty((n, TOPK), dtype=torch.int32, device=dev)
+    scores = torch.empty((n, TOPK), dtype=torch.float32, device=dev)
+    h_ids = torch.empty((n, TOPK), dtype=torch.int32).pin_memory()
+    h_scores = torch.empty((n, TOPK), dtype=torch.float32).pin_memory()
+
+    def step():
+        sc.rank_topk(users, TOPK, ids, scores)
+        per_user, evaluated, sums = sc.eval_topk_metrics(users, ids, [TOPK])
+        if world > 1:
+            dist.all_reduce(sums)                      # RCCL: [sum ndcg, sum recall, sum precision, n_evaluated]
+        h_ids.copy_(ids, non_blocking=True)
+        h_scores.copy_(scores, non_blocking=True)
+        return sums
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    sc.profile_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        sums = step()
+    fence()
+    dt = time.perf_counter() - t0
+    sc.profile_enable(False)
+    kern_ms, launches, pairs = sc.profile_read()
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    if rank == 0:
+        sums = sums.cpu().numpy()
+        flops_per_launch = 2.0 * n * w["n_items"] * w["k"]           # 2*I*k per user x users per launch
+        avg_ms = kern_ms / max(launches, 1)
+        achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12
+        out = {
+            "metric": "users ranked/sec (full-catalogue top-10 + NDCG/Recall)",
+            "value": world * n * args.steps / dt,
+            "unit": "users/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"{args.config}: WMF-style dot-product model, {n} users/GPU x {w['n_items']} items, "
+                                   f"k={w['k']}, top-{TOPK} + NDCG@{TOPK}/Recall@{TOPK}/Precision@{TOPK}",
+                       "users_per_gpu": n, "items": w["n_items"], "k": w["k"], "topk": TOPK,
+                       "parallelism": f"users sharded x{world}, item factors replicated"},
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                         "kernel": "score_topk_kernel", "avg_launch_ms": avg_ms, "launches": launches,
+                         "flops_per_launch": flops_per_launch},
+            "eval": {"ndcg@10": sums[0] / sums[3], "recall@10": sums[1] / sums[3], "precision@10": sums[2] / sums[3],
+                     "n_evaluated": float(sums[3])},
+        }
+        if world == 1 and not args.no_cpu:
+            base, o_ids, _, _ = cpu_baseline(w, min(args.cpu_sample, n), sc.chain_order())
+            out["cpu_baseline"] = base
+            m = min(args.cpu_sample, n)
+            out["parity_on_cpu_sample"] = {"users": m, "top10_ids_equal": bool((h_ids[:m].numpy() == o_ids).all())}
+            out["cpu_baseline_strong"] = cpu_strong(w, min(2048, n))
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
