@@ -51,6 +51,7 @@ struct ifr_handle_s {
     // tuning
     int opt_chunks = 0;          // 0 = heuristic
     int opt_target_blocks = 4096;
+    int opt_debug = 0;           // dev-only kernel ablation mode (see TopkParams::dbg)
     // profiling
     bool prof = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_used, ev_free;
@@ -170,6 +171,7 @@ int ifr_set_option(ifr_handle h, const char *name, int64_t value)
 {
     if (!h || !name) return IFR_ERR_ARG;
     if (!strcmp(name, "chunks")) h->opt_chunks = (int)value;
+    else if (!strcmp(name, "debug_mode")) h->opt_debug = (int)value;
     else if (!strcmp(name, "target_blocks")) h->opt_target_blocks = (int)std::max<int64_t>(1, value);
     else return fail(h, IFR_ERR_ARG, std::string("unknown option ") + name);
     return IFR_OK;
@@ -285,6 +287,7 @@ int ifr_rank_topk(ifr_handle h, const int32_t *user_ids, int64_t n, int K, int32
     p.user_ids = user_ids; p.n = n; p.n_items = (int)h->n_items; p.n_tiles = h->n_tiles;
     p.chunk_tiles = chunk_tiles; p.n_chunks = n_chunks; p.K = K;
     p.ex_ptr = h->ex_ptr; p.ex_cnt = h->ex_cnt; p.ex_tile = h->ex_tile; p.ex_mask = h->ex_mask; p.ex_rows = h->ex_rows;
+    p.dbg = h->opt_debug;
     p.part_scores = (float *)h->ws_part;
     p.part_ids = (int32_t *)((char *)h->ws_part + entries * 4);
 

@@ -46,6 +46,7 @@ struct TopkParams {
     int64_t ex_rows;
     float *part_scores;      // [n_slots][n_chunks*2][KL]
     int32_t *part_ids;
+    int dbg;                 // dev-only ablation switch: 0 = normal, 1 = no select, 2 = filter only (never hits)
 };
 
 // item row inside a 32x32 accumulator block held by register r of a lane in half h
@@ -210,11 +211,17 @@ __global__ __launch_bounds__(BLOCK, 2) void score_topk_kernel(TopkParams p)
         }
 
         // ---- threshold filter: one max-reduce per lane, then a wave vote
+        if (p.dbg == 1) {                       // ablation: MFMA + staging only (keep acc live)
+            if (s[0] == 12345.678f && s[7] == 3.0f && s[15] == 1.0f) p.part_ids[0] = t;
+            if (t + 1 < t1) stage_store(buf ^ 1);
+            __syncthreads();
+            continue;
+        }
         float mx = fmaxf(fmaxf(s[0], s[1]), s[2]);
 #pragma unroll
         for (int r = 3; r + 1 < 16; r += 2) mx = fmaxf(fmaxf(mx, s[r]), s[r + 1]);
         mx = fmaxf(mx, s[15]);
-        if (__any(mx > tau)) {
+        if (__any(mx > tau) && p.dbg != 2) {
             uint32_t hits = 0;
 #pragma unroll
             for (int r = 0; r < 16; ++r) hits |= (s[r] > tau ? 1u : 0u) << r;
