@@ -51,6 +51,7 @@ struct ifr_handle_s {
     // tuning
     int opt_chunks = 0;          // 0 = heuristic
     int opt_target_blocks = 4096;
+    int opt_share_bounds = 1;    // share per-user lower bounds between item chunks
     int opt_debug = 0;           // dev-only kernel ablation mode (see TopkParams::dbg)
     // profiling
     bool prof = false;
@@ -171,6 +172,7 @@ int ifr_set_option(ifr_handle h, const char *name, int64_t value)
 {
     if (!h || !name) return IFR_ERR_ARG;
     if (!strcmp(name, "chunks")) h->opt_chunks = (int)value;
+    else if (!strcmp(name, "share_bounds")) h->opt_share_bounds = (int)value;
     else if (!strcmp(name, "debug_mode")) h->opt_debug = (int)value;
     else if (!strcmp(name, "target_blocks")) h->opt_target_blocks = (int)std::max<int64_t>(1, value);
     else return fail(h, IFR_ERR_ARG, std::string("unknown option ") + name);
@@ -280,7 +282,8 @@ int ifr_rank_topk(ifr_handle h, const int32_t *user_ids, int64_t n, int K, int32
     const int64_t grid = n_ut * n_chunks;
     if (grid > 0x7fffffff) return fail(h, IFR_ERR_ARG, "ifr_rank_topk: batch too large, split the user list");
     const size_t entries = (size_t)n * n_chunks * 2 * KL;
-    int rc = grow(h, &h->ws_part, &h->ws_part_bytes, entries * 8);
+    const size_t lb_bytes = (size_t)n_ut * ifr::USERS_PER_BLOCK * sizeof(uint32_t);
+    int rc = grow(h, &h->ws_part, &h->ws_part_bytes, entries * 8 + lb_bytes);
     if (rc) return rc;
     ifr::TopkParams p;
     p.U = h->U; p.V = h->V; p.ibase = h->ibase; p.ubase = h->ubase;
@@ -290,6 +293,8 @@ int ifr_rank_topk(ifr_handle h, const int32_t *user_ids, int64_t n, int K, int32
     p.dbg = h->opt_debug;
     p.part_scores = (float *)h->ws_part;
     p.part_ids = (int32_t *)((char *)h->ws_part + entries * 4);
+    p.lb = h->opt_share_bounds ? (uint32_t *)((char *)h->ws_part + entries * 8) : nullptr;
+    if (p.lb) IFR_HIP(h, hipMemsetAsync(p.lb, 0, lb_bytes, s));
 
     std::pair<hipEvent_t, hipEvent_t> ev;
     if (h->prof) {

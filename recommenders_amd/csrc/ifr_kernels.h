@@ -46,11 +46,33 @@ struct TopkParams {
     int64_t ex_rows;
     float *part_scores;      // [n_slots][n_chunks*2][KL]
     int32_t *part_ids;
+    uint32_t *lb;            // [n_slots padded to 128] per-user lower-bound keys, zeroed per call (may be null)
     int dbg;                 // dev-only ablation switch: 0 = normal, 1 = no select, 2 = filter only (never hits)
 };
 
 // item row inside a 32x32 accumulator block held by register r of a lane in half h
 __device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+// float <-> order-preserving uint32 key (0 is below every float: "no bound yet")
+__device__ __forceinline__ uint32_t float_to_key(float x)
+{
+    const uint32_t b = __float_as_uint(x);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float key_to_float(uint32_t k)
+{
+    if (k == 0) return -INFINITY;
+    return __uint_as_float((k & 0x80000000u) ? (k ^ 0x80000000u) : ~k);
+}
+// largest float strictly below x (so that  s > next_below(x)  <=>  s >= x); -inf and NaN map to -inf
+__device__ __forceinline__ float next_below(float x)
+{
+    if (!(x > -INFINITY)) return -INFINITY;
+    uint32_t b = __float_as_uint(x);
+    if ((b << 1) == 0) return __uint_as_float(0x80000001u);      // +-0 -> -denorm_min
+    b = (b & 0x80000000u) ? b + 1 : b - 1;
+    return __uint_as_float(b);
+}
 
 // Sorted insertion into a lane-private descending list.  Strict '>' keeps earlier (smaller
 // item index) entries ahead of later equal scores, which is the canonical tie order because a
@@ -62,7 +84,8 @@ __device__ __forceinline__ void list_insert(float (&ls)[KL], int (&li)[KL], floa
     for (int i = KL - 1; i >= 1; --i) {
         const bool ci = x > ls[i];
         const bool cim = x > ls[i - 1];
-        li[i] = ci ? (cim ? li[i - 1] : id) : li[i];
+        const int take = cim ? li[i - 1] : id;
+        li[i] = ci ? take : li[i];
         ls[i] = __builtin_amdgcn_fmed3f(x, ls[i - 1], ls[i]);
     }
     li[0] = (x > ls[0]) ? id : li[0];
@@ -139,6 +162,28 @@ __global__ __launch_bounds__(BLOCK, 2) void score_topk_kernel(TopkParams p)
     for (int i = 0; i < KL; ++i) { ls[i] = -INFINITY; li[i] = NO_TILE; }
     float tau = -INFINITY;
     int cnt = 0;
+    // A lower bound L on the user's K-th best score (from the partner half-lane or from another
+    // item chunk's workgroup, via p.lb) prunes with '>=': s > next_below(L).  The lane's own K-th
+    // best prunes with '>' (its list only holds earlier, smaller item ids).
+    if (p.lb != nullptr) tau = next_below(key_to_float(p.lb[slot]));
+    auto flush = [&]() {
+        int maxc = cnt;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) maxc = max(maxc, __shfl_xor(maxc, off));
+        for (int q = 0; q < maxc; ++q) {
+            const uint2 e = pend[q][tid];
+            const float x = (q < cnt) ? __uint_as_float(e.x) : -INFINITY;     // -inf never inserts
+            list_insert<KL>(ls, li, x, (int)e.y);
+        }
+        cnt = 0;
+        const float own = list_tau<KL>(ls, p.K);
+        float ext = __shfl_xor(own, 32);
+        if (p.lb != nullptr) {
+            const uint32_t old = atomicMax(&p.lb[slot], float_to_key(own));
+            ext = fmaxf(ext, key_to_float(old));
+        }
+        tau = fmaxf(fmaxf(own, next_below(ext)), tau);
+    };
 
     // ---- stage tile t0 into buffer 0
     f32x4 st[STAGE];
@@ -222,29 +267,28 @@ __global__ __launch_bounds__(BLOCK, 2) void score_topk_kernel(TopkParams p)
         for (int r = 3; r + 1 < 16; r += 2) mx = fmaxf(fmaxf(mx, s[r]), s[r + 1]);
         mx = fmaxf(mx, s[15]);
         if (__any(mx > tau) && p.dbg != 2) {
-            uint32_t hits = 0;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) hits |= (s[r] > tau ? 1u : 0u) << r;
-            if (__any(cnt + __popc(hits) > PEND)) {
-                // drain the pending slots into the register lists, raise tau, re-filter
-                for (int q = 0; __any(q < cnt); ++q) {
-                    if (q < cnt) {
-                        const uint2 e = pend[q][tid];
-                        list_insert<KL>(ls, li, __uint_as_float(e.x), (int)e.y);
-                    }
-                }
-                cnt = 0;
-                tau = list_tau<KL>(ls, p.K);
-                hits = 0;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) hits |= (s[r] > tau ? 1u : 0u) << r;
-            }
             const int item0 = t * TILE_I + 4 * h;
+            uint32_t todo = 0;                  // hits that found the lane's pending slots full
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                if (hits & (1u << r)) {
-                    pend[cnt][tid] = make_uint2(__float_as_uint(s[r]), (uint32_t)(item0 + (r & 3) + 8 * (r >> 2)));
-                    ++cnt;
+                if (s[r] > tau) {
+                    if (cnt < PEND) {
+                        pend[cnt][tid] = make_uint2(__float_as_uint(s[r]), (uint32_t)(item0 + (r & 3) + 8 * (r >> 2)));
+                        ++cnt;
+                    } else {
+                        todo |= 1u << r;
+                    }
+                }
+            }
+            if (__any(todo != 0)) {
+                // drain every lane's pending slots into its register list, raise tau, retry the rest
+                flush();
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    if ((todo & (1u << r)) && s[r] > tau) {
+                        pend[cnt][tid] = make_uint2(__float_as_uint(s[r]), (uint32_t)(item0 + (r & 3) + 8 * (r >> 2)));
+                        ++cnt;
+                    }
                 }
             }
         }
@@ -254,12 +298,7 @@ __global__ __launch_bounds__(BLOCK, 2) void score_topk_kernel(TopkParams p)
     }
 
     // ---- final drain and write the lane's partial list
-    for (int q = 0; __any(q < cnt); ++q) {
-        if (q < cnt) {
-            const uint2 e = pend[q][tid];
-            list_insert<KL>(ls, li, __uint_as_float(e.x), (int)e.y);
-        }
-    }
+    flush();
     if (live) {
         const int64_t base = ((slot * p.n_chunks + chunk) * 2 + h) * KL;
 #pragma unroll
