@@ -116,6 +116,7 @@ __global__ __launch_bounds__(BLOCK, 2) void score_topk_kernel(TopkParams p)
     constexpr int STAGE = (TILE_I * C4) / BLOCK; // float4 loads per thread per tile
     static_assert((TILE_I * C4) % BLOCK == 0, "tile must split evenly");
     __shared__ __attribute__((aligned(16))) float vt[2][TILE_I][ROW];
+    __shared__ __attribute__((aligned(16))) float ibt[2][TILE_I];
     __shared__ uint2 pend[PEND][BLOCK];
 
     const int tid = threadIdx.x;
@@ -185,7 +186,7 @@ __global__ __launch_bounds__(BLOCK, 2) void score_topk_kernel(TopkParams p)
         tau = fmaxf(fmaxf(own, next_below(ext)), tau);
     };
 
-    // ---- stage tile t0 into buffer 0
+    // ---- item-factor tiles: global -> registers -> LDS, double buffered
     f32x4 st[STAGE];
     float st_b = 0.0f;
     auto stage_load = [&](int t) {
@@ -202,81 +203,86 @@ __global__ __launch_bounds__(BLOCK, 2) void score_topk_kernel(TopkParams p)
             const int row = idx / C4, c4 = idx - row * C4;
             *reinterpret_cast<f32x4 *>(&vt[buf][row][c4 * 4]) = st[q];
         }
-        if (HAS_BASE && tid < TILE_I) vt[buf][tid][KD] = st_b;
+        if (HAS_BASE && tid < TILE_I) ibt[buf][tid] = st_b;
     };
     if (t0 < t1) { stage_load(t0); stage_store(0); }
     __syncthreads();
 
-    for (int t = t0; t < t1; ++t) {
+    // Software pipeline: iteration t issues the MFMAs of tile t and, in the same basic block,
+    // runs the branch-free select of tile t-1 (bias add, exclusion, threshold test, predicated
+    // append), so the VALU/LDS work of the select fills the issue gaps of the matrix pipe.
+    // Iteration t0 selects nothing (threshold +inf); iteration t1 multiplies a stale tile whose
+    // result is dropped.
+    f32x16 accC = {0};
+    float ibC[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ibC[r] = 0.0f;
+    uint32_t mC = 0;
+    for (int t = t0; t <= t1; ++t) {
         const int buf = (t - t0) & 1;
         if (t + 1 < t1) stage_load(t + 1);
 
-        // ---- 32 items x 32 users x KD on the matrix core
-        f32x16 acc = {0};
+        // ---- zone A: 32 items x 32 users x KD on the matrix core (tile t), one k-group of four
+        // MFMAs per step, each step followed by the branch-free part of the select for 128/KD score
+        // registers of tile t-1: bias add, exclusions (and rows past n_items) turned into NaN, which
+        // never compares '>', and a running max per 4-register group.  sched_barrier(0) keeps the
+        // steps apart so this VALU work issues while the step's last MFMA is still in the pipe.
+        constexpr int G = KD / 8;               // k-groups per tile
+        constexpr int RPG = 16 / G;             // score registers selected per k-group
+        f32x16 accN = {0};
+        float ibN[16];
         const float *arow = &vt[buf][j][4 * h];
+        const float seltau = (t > t0 && p.dbg != 2) ? tau : INFINITY;
+        const int item0 = (t - 1) * TILE_I + 4 * h;
+        const uint32_t mm = mC >> (4 * h);
+        float s[16], gmx[4];
+        f32x4 a_cur = *reinterpret_cast<const f32x4 *>(arow);
 #pragma unroll
-        for (int g = 0; g < KD / 8; ++g) {
-            const f32x4 a4 = *reinterpret_cast<const f32x4 *>(arow + 8 * g);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[0], ureg[g][0], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[1], ureg[g][1], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[2], ureg[g][2], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[3], ureg[g][3], acc, 0, 0, 0);
-        }
-
-        float s[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            if (HAS_BASE) {
-                const float base = vt[buf][acc_row(r, h)][KD] + ub;   // (ibase + ubase) + dot
-                s[r] = base + acc[r];
-            } else {
-                s[r] = acc[r];
+        for (int g = 0; g < G; ++g) {
+            f32x4 a_nxt = a_cur;
+            if (g + 1 < G) a_nxt = *reinterpret_cast<const f32x4 *>(arow + 8 * (g + 1));
+            if (HAS_BASE && g < 4) {
+                const f32x4 b4 = *reinterpret_cast<const f32x4 *>(&ibt[buf][8 * g + 4 * h]);
+                ibN[4 * g + 0] = b4[0]; ibN[4 * g + 1] = b4[1]; ibN[4 * g + 2] = b4[2]; ibN[4 * g + 3] = b4[3];
             }
-        }
-
-        // ---- exclusions (and rows past n_items) become NaN: they never compare '>'
-        uint32_t m = 0;
-        if (nt == t) {
-            m = nm;
-            ++ex_cur;
-            if (ex_cur < ex_end) { nt = p.ex_tile[ex_cur]; nm = p.ex_mask[ex_cur]; } else nt = NO_TILE;
-        }
-        if (t == p.n_tiles - 1) {
-            const int valid = p.n_items - t * TILE_I;       // 1..32
-            if (valid < 32) m |= ~0u << valid;
-        }
-        if (__any(m != 0)) {
-            const uint32_t mm = m >> (4 * h);
+            accN = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[0], ureg[g][0], accN, 0, 0, 0);
+            accN = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[1], ureg[g][1], accN, 0, 0, 0);
+            accN = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[2], ureg[g][2], accN, 0, 0, 0);
+            accN = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[3], ureg[g][3], accN, 0, 0, 0);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
+            for (int r = g * RPG; r < (g + 1) * RPG; ++r) {
                 const int bit = (r & 3) + 8 * (r >> 2);
-                const uint32_t kill = (uint32_t)(-(int32_t)((mm >> bit) & 1u));   // 0 or ~0
-                s[r] = __uint_as_float(__float_as_uint(s[r]) | (kill & 0xFFC00000u));
+                float sc = HAS_BASE ? ((ibC[r] + ub) + accC[r]) : accC[r];      // (ibase + ubase) + dot
+                const uint32_t kill = (uint32_t)(-(int32_t)((mm >> bit) & 1u)); // 0 or ~0
+                sc = __uint_as_float(__float_as_uint(sc) | (kill & 0xFFC00000u));
+                s[r] = sc;
+                gmx[r >> 2] = (r & 3) ? fmaxf(gmx[r >> 2], sc) : sc;            // max of each 4-register group
             }
+            a_cur = a_nxt;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (!HAS_BASE) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ibN[r] = 0.0f;
         }
 
-        // ---- threshold filter: one max-reduce per lane, then a wave vote
-        if (p.dbg == 1) {                       // ablation: MFMA + staging only (keep acc live)
-            if (s[0] == 12345.678f && s[7] == 3.0f && s[15] == 1.0f) p.part_ids[0] = t;
-            if (t + 1 < t1) stage_store(buf ^ 1);
-            __syncthreads();
-            continue;
-        }
-        float mx = fmaxf(fmaxf(s[0], s[1]), s[2]);
-#pragma unroll
-        for (int r = 3; r + 1 < 16; r += 2) mx = fmaxf(fmaxf(mx, s[r]), s[r + 1]);
-        mx = fmaxf(mx, s[15]);
-        if (__any(mx > tau) && p.dbg != 2) {
-            const int item0 = t * TILE_I + 4 * h;
+        // ---- zone B: threshold vote; only groups (4 registers) that hold a hit are scanned
+        const float mx = fmaxf(fmaxf(gmx[0], gmx[1]), fmaxf(gmx[2], gmx[3]));
+        if (__any(mx > seltau)) {
             uint32_t todo = 0;                  // hits that found the lane's pending slots full
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                if (s[r] > tau) {
-                    if (cnt < PEND) {
-                        pend[cnt][tid] = make_uint2(__float_as_uint(s[r]), (uint32_t)(item0 + (r & 3) + 8 * (r >> 2)));
-                        ++cnt;
-                    } else {
-                        todo |= 1u << r;
+            for (int q = 0; q < 4; ++q) {
+                if (gmx[q] > seltau) {
+#pragma unroll
+                    for (int r = 4 * q; r < 4 * q + 4; ++r) {
+                        if (s[r] > seltau) {
+                            if (cnt < PEND) {
+                                pend[cnt][tid] = make_uint2(__float_as_uint(s[r]), (uint32_t)(item0 + (r & 3) + 8 * q));
+                                ++cnt;
+                            } else {
+                                todo |= 1u << r;
+                            }
+                        }
                     }
                 }
             }
@@ -292,7 +298,20 @@ __global__ __launch_bounds__(BLOCK, 2) void score_topk_kernel(TopkParams p)
                 }
             }
         }
-
+        // exclusion mask of tile t for the next iteration's select
+        mC = 0;
+        if (nt == t) {
+            mC = nm;
+            ++ex_cur;
+            if (ex_cur < ex_end) { nt = p.ex_tile[ex_cur]; nm = p.ex_mask[ex_cur]; } else nt = NO_TILE;
+        }
+        if (t == p.n_tiles - 1) {
+            const int valid = p.n_items - t * TILE_I;       // 1..32
+            if (valid < 32) mC |= ~0u << valid;
+        }
+        accC = accN;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ibC[r] = ibN[r];
         if (t + 1 < t1) stage_store(buf ^ 1);
         __syncthreads();
     }

@@ -23,14 +23,9 @@ def main():
         torch.cuda.synchronize()
         ms, l, _ = sc.profile_read(); sc.profile_enable(False)
         print(f"{tag:40s} {ms/l:8.3f} ms  {flops/(ms/l*1e-3)/1e12:7.1f} TF", flush=True)
-    for share in (1, 0):
-        sc.set_option("share_bounds", share)
-        for ch in (1, 2, 3, 4, 6, 8, 16):
+    for dbg in (0, 2):
+        sc.set_option("debug_mode", dbg)
+        for ch in (1, 2, 3, 4, 6, 8):
             sc.set_option("chunks", ch)
-            run(f"share={share} chunks={ch}")
-    sc.set_option("share_bounds", 1)
-    sc.set_option("debug_mode", 1)
-    for ch in (2, 4, 8):
-        sc.set_option("chunks", ch)
-        run(f"dbg=1 chunks={ch}")
+            run(f"dbg={dbg} chunks={ch}")
 main()
