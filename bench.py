@@ -67,7 +67,7 @@ def main():
     ap.add_argument("--config", default="c2_wmf_ml20m")
     ap.add_argument("--users", type=int, default=None, help="override users per rank (debug only)")
     ap.add_argument("--items", type=int, default=None, help="override catalogue size (debug only)")
-    ap.add_argument("--cpu-sample", type=int, default=4096)
+    ap.add_argument("--cpu-sample", type=int, default=65536)
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
 
@@ -102,7 +102,7 @@ def main():
         sc.rank_topk(users, TOPK, ids, scores)
         per_user, evaluated, sums = sc.eval_topk_metrics(users, ids, [TOPK])
         if world > 1:
-            dist.all_reduce(sums)                      # RCCL: [sum ndcg, sum recall, sum precision, n_evaluated]
+            dist.all_reduce(sums)                      # RCCL: per-metric sums + evaluated-user count
         h_ids.copy_(ids, non_blocking=True)
         h_scores.copy_(scores, non_blocking=True)
         return sums
@@ -155,8 +155,8 @@ def main():
                          "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
                          "kernel": "score_topk_kernel", "avg_launch_ms": avg_ms, "launches": launches,
                          "flops_per_launch": flops_per_launch},
-            "eval": {"ndcg@10": sums[0] / sums[3], "recall@10": sums[1] / sums[3], "precision@10": sums[2] / sums[3],
-                     "n_evaluated": float(sums[3])},
+            "eval": {"ndcg@10": sums[0] / sums[-1], "recall@10": sums[1] / sums[-1],
+                     "precision@10": sums[2] / sums[-1], "n_evaluated": float(sums[-1])},
         }
         if world == 1 and not args.no_cpu:
             base, o_ids, _, _ = cpu_baseline(w, min(args.cpu_sample, n), sc.chain_order())

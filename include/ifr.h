@@ -80,17 +80,30 @@ int ifr_set_truth_csr(ifr_handle h, const int64_t *indptr, const int32_t *indice
 int ifr_rank_topk(ifr_handle h, const int32_t *user_ids, int64_t n, int K,
                   int32_t *out_ids, float *out_scores, void *stream);
 
-/* Ranking metrics from top-K lists against the truth CSR.  Replaces NDCG.compute,
- * Precision.compute and Recall.compute (cornac/metrics/ranking.py:100-123, 329-349, 366-386)
- * and the per-user loop + mean of ranking_eval (cornac/eval_methods/base_method.py:291-303).
- * ks: host array of n_k cut-offs, each 1 <= ks[j] <= K.  out_per_user: dev [n][3*n_k]
- * (ndcg, recall, precision per cut-off; NaN rows for users without a test positive, which
- * the reference skips, :258-259).  evaluated: dev [n] 0/1.  out_sums: dev [3*n_k + 1] =
- * column sums over evaluated users followed by their count (the operands of one
- * all-reduce in the multi-GPU path). */
+#define IFR_METRICS_PER_K 6  /* per cut-off: ndcg, recall, precision, hit ratio, f1, ncrr */
+
+/* Ranking metrics from top-K lists against the truth CSR.  Replaces NDCG.compute, Recall.compute,
+ * Precision.compute, HitRatio.compute, FMeasure.compute and NCRR.compute
+ * (cornac/metrics/ranking.py:100-123, 366-386, 329-349, 291-312, 403-431, 140-180) and the
+ * per-user loop + mean of ranking_eval (cornac/eval_methods/base_method.py:291-303).
+ * ks: host array of n_k cut-offs, each 1 <= ks[j] <= K <= 32.  out_per_user: dev
+ * [n][IFR_METRICS_PER_K*n_k] (NaN rows for users without a test positive, which the reference
+ * skips, :258-259).  evaluated: dev [n] 0/1.  out_sums: dev [IFR_METRICS_PER_K*n_k + 1] = column
+ * sums over evaluated users followed by their count (the operands of one all-reduce in the
+ * multi-GPU path). */
 int ifr_eval_topk_metrics(ifr_handle h, const int32_t *user_ids, int64_t n,
                           const int32_t *topk_ids, int K, const int32_t *ks, int n_k,
                           double *out_per_user, int32_t *evaluated, double *out_sums, void *stream);
+
+/* The same metrics from full ranked lists, for cut-offs of any size and ks[j] = -1 (whole list),
+ * plus two per-user columns after the per-cut-off block: reciprocal rank of the first hit (MRR,
+ * cornac/metrics/ranking.py:194-223; NaN when nothing matches, where the reference raises) and
+ * average precision (MAP, :500-527, on a tie-free ranking).  ranked: dev [n][ld] item ids in
+ * rank order, n_ranked: dev [n] valid entries per row.  out_per_user: dev
+ * [n][IFR_METRICS_PER_K*n_k + 2]; out_sums: dev [IFR_METRICS_PER_K*n_k + 3]. */
+int ifr_eval_ranked_metrics(ifr_handle h, const int32_t *user_ids, int64_t n, const int32_t *ranked,
+                            int64_t ld, const int32_t *n_ranked, const int32_t *ks, int n_k,
+                            double *out_per_user, int32_t *evaluated, double *out_sums, void *stream);
 
 /* Full score rows for a batch of users (bit-identical to the scores the fused kernel ranks).
  * Replaces Recommender.score(user_idx) (cornac/models/recommender.py:480-498) /
@@ -110,6 +123,13 @@ int ifr_auc_dense(ifr_handle h, const int32_t *user_ids, int64_t n, const float 
  * valid, rest -1); n_cand: dev [n]. */
 int ifr_rank_full(ifr_handle h, const int32_t *user_ids, int64_t n, const float *scores,
                   int64_t ld, int32_t *out_ids, int32_t *n_cand, void *stream);
+
+/* Order an arbitrary candidate list by one user's scores (score descending, item index
+ * ascending).  Replaces `item_indices[item_scores.argsort()[::-1]]` of Recommender.rank for a
+ * caller-supplied item_indices (cornac/models/recommender.py:638-652).  scores: dev [n_scores]
+ * indexed by item id; items: dev [m]; out_ids: dev [m]. */
+int ifr_rank_items(ifr_handle h, const float *scores, int64_t n_scores, const int32_t *items, int64_t m,
+                   int32_t *out_ids, void *stream);
 
 /* Kernel timing with HIP events on the launch stream (used by bench.py for the roofline
  * figure; no reference counterpart).  After ifr_profile_enable(h, 1) every ifr_rank_topk

@@ -20,6 +20,8 @@ int launch_auc(const float *scores, int64_t ld, const int32_t *user_ids, int64_t
                const int64_t *ex_ptr, const int32_t *ex_idx, int64_t ex_rows,
                const int64_t *tr_ptr, const int32_t *tr_idx, int64_t tr_rows,
                double *out, hipStream_t stream);
+int launch_rank_items(const float *scores, int64_t n_scores, const int32_t *items, int64_t m, int32_t *out_ids,
+                      void **ws, size_t *ws_bytes, hipStream_t stream);
 int launch_rank_full(const float *scores, int64_t ld, const int32_t *user_ids, int64_t n, int n_items,
                      const int64_t *ex_ptr, const int32_t *ex_idx, int64_t ex_rows,
                      int32_t *out_ids, int32_t *n_cand, void **ws, size_t *ws_bytes, hipStream_t stream);
@@ -321,6 +323,19 @@ int ifr_rank_topk(ifr_handle h, const int32_t *user_ids, int64_t n, int K, int32
     return IFR_OK;
 }
 
+static int sum_columns(ifr_handle h, const double *per_user, const int32_t *evaluated, int64_t n, int ncol,
+                       double *out_sums, hipStream_t s)
+{
+    if (ncol + 1 > 64) return fail(h, IFR_ERR_ARG, "too many metric columns");
+    const int grid = (int)((n + ifr::COLSUM_ROWS - 1) / ifr::COLSUM_ROWS);
+    int rc = grow(h, &h->ws_met, &h->ws_met_bytes, sizeof(double) * (size_t)grid * (ncol + 1));
+    if (rc) return rc;
+    hipLaunchKernelGGL(ifr::colsum_kernel, dim3(grid), dim3(64), 0, s, per_user, evaluated, n, ncol, (double *)h->ws_met);
+    hipLaunchKernelGGL(ifr::reduce_sums_kernel, dim3(1), dim3(64), 0, s, (const double *)h->ws_met, grid, ncol + 1, out_sums);
+    IFR_HIP(h, hipGetLastError());
+    return IFR_OK;
+}
+
 int ifr_eval_topk_metrics(ifr_handle h, const int32_t *user_ids, int64_t n, const int32_t *topk_ids, int K,
                           const int32_t *ks, int n_k, double *out_per_user, int32_t *evaluated, double *out_sums,
                           void *stream)
@@ -336,18 +351,48 @@ int ifr_eval_topk_metrics(ifr_handle h, const int32_t *user_ids, int64_t n, cons
     IFR_HIP(h, hipSetDevice(h->device));
     hipStream_t s = (hipStream_t)stream;
     const int grid = (int)((n + ifr::BLOCK - 1) / ifr::BLOCK);
-    const int ncol1 = 3 * n_k + 1;
-    int rc = grow(h, &h->ws_met, &h->ws_met_bytes, sizeof(double) * (size_t)grid * ncol1);
-    if (rc) return rc;
     ifr::MetricParams p;
     p.user_ids = user_ids; p.n = n; p.topk = topk_ids; p.K = K; p.n_k = n_k;
     for (int q = 0; q < ifr::MAX_KS; ++q) p.ks[q] = q < n_k ? ks[q] : 0;
     p.tr_ptr = h->tr_ptr; p.tr_idx = h->tr_idx; p.tr_rows = h->tr_rows;
     p.discount = h->discount; p.per_user = out_per_user; p.evaluated = evaluated;
-    p.block_sums = (double *)h->ws_met;
-    hipLaunchKernelGGL(ifr::metrics_kernel, dim3(grid), dim3(ifr::BLOCK), 0, s, p);
-    hipLaunchKernelGGL(ifr::reduce_sums_kernel, dim3(1), dim3(64), 0, s, p.block_sums, grid, ncol1, out_sums);
+    hipLaunchKernelGGL(ifr::metrics_topk_kernel, dim3(grid), dim3(ifr::BLOCK), 0, s, p);
     IFR_HIP(h, hipGetLastError());
+    return sum_columns(h, out_per_user, evaluated, n, IFR_METRICS_PER_K * n_k, out_sums, s);
+}
+
+int ifr_eval_ranked_metrics(ifr_handle h, const int32_t *user_ids, int64_t n, const int32_t *ranked, int64_t ld,
+                            const int32_t *n_ranked, const int32_t *ks, int n_k, double *out_per_user,
+                            int32_t *evaluated, double *out_sums, void *stream)
+{
+    if (!h) return IFR_ERR_ARG;
+    if (!h->tr_ptr) return fail(h, IFR_ERR_STATE, "ifr_eval_ranked_metrics: truth CSR not set");
+    if (!user_ids || !ranked || !n_ranked || !ks || !out_per_user || !evaluated || !out_sums || n <= 0 || ld <= 0)
+        return fail(h, IFR_ERR_ARG, "ifr_eval_ranked_metrics: null/empty argument");
+    if (n_k < 1 || n_k > ifr::MAX_KS) return fail(h, IFR_ERR_ARG, "ifr_eval_ranked_metrics: n_k in [1,8]");
+    for (int q = 0; q < n_k; ++q)
+        if (ks[q] == 0 || ks[q] < -1) return fail(h, IFR_ERR_ARG, "ifr_eval_ranked_metrics: cut-off must be -1 or > 0");
+    IFR_HIP(h, hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)stream;
+    ifr::ListMetricParams p;
+    p.user_ids = user_ids; p.n = n; p.ranked = ranked; p.ld = ld; p.n_ranked = n_ranked; p.n_k = n_k;
+    for (int q = 0; q < ifr::MAX_KS; ++q) p.ks[q] = q < n_k ? ks[q] : 1;
+    p.tr_ptr = h->tr_ptr; p.tr_idx = h->tr_idx; p.tr_rows = h->tr_rows;
+    p.per_user = out_per_user; p.evaluated = evaluated;
+    hipLaunchKernelGGL(ifr::metrics_list_kernel, dim3((unsigned)n), dim3(ifr::BLOCK), 0, s, p);
+    IFR_HIP(h, hipGetLastError());
+    return sum_columns(h, out_per_user, evaluated, n, IFR_METRICS_PER_K * n_k + 2, out_sums, s);
+}
+
+int ifr_rank_items(ifr_handle h, const float *scores, int64_t n_scores, const int32_t *items, int64_t m,
+                   int32_t *out_ids, void *stream)
+{
+    if (!h) return IFR_ERR_ARG;
+    if (m == 0) return IFR_OK;
+    if (!scores || !items || !out_ids || m < 0 || n_scores <= 0) return fail(h, IFR_ERR_ARG, "ifr_rank_items: bad argument");
+    IFR_HIP(h, hipSetDevice(h->device));
+    int rc = ifr::launch_rank_items(scores, n_scores, items, m, out_ids, &h->ws_sort, &h->ws_sort_bytes, (hipStream_t)stream);
+    if (rc) return fail(h, rc, "ifr_rank_items: sort failed");
     return IFR_OK;
 }
 

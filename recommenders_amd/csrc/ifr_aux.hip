@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_segmented_radix_sort.hpp>
 #include <rocprim/iterator/counting_iterator.hpp>
 #include <rocprim/iterator/transform_iterator.hpp>
@@ -137,6 +138,46 @@ __global__ void keys_to_ids_kernel(const uint64_t *keys, int n_items, int64_t ld
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= ld) return;
     out[i * ld + r] = (r < n_cand[i]) ? (int32_t)(uint32_t)keys[i * n_items + r] : -1;
+}
+
+__global__ void build_item_keys_kernel(const float *scores, int64_t n_scores, const int32_t *items, int64_t m, uint64_t *keys)
+{
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= m) return;
+    const int it = items[q];
+    const float s = (it >= 0 && it < n_scores) ? scores[it] : -INFINITY;
+    keys[q] = ((uint64_t)desc_key(s) << 32) | (uint32_t)it;
+}
+
+__global__ void item_keys_to_ids_kernel(const uint64_t *keys, int64_t m, int32_t *out)
+{
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q < m) out[q] = (int32_t)(uint32_t)keys[q];
+}
+
+// Order an arbitrary candidate list of one user by (score descending, item index ascending).
+int launch_rank_items(const float *scores, int64_t n_scores, const int32_t *items, int64_t m, int32_t *out_ids,
+                      void **ws, size_t *ws_bytes, hipStream_t stream)
+{
+    const size_t key_bytes = sizeof(uint64_t) * (size_t)m;
+    size_t tmp_bytes = 0;
+    uint64_t *null_keys = nullptr;
+    if (rocprim::radix_sort_keys(nullptr, tmp_bytes, null_keys, null_keys, (size_t)m, 0, 64, stream) != hipSuccess) return -3;
+    const size_t need = 2 * key_bytes + tmp_bytes + 512;
+    if (*ws_bytes < need) {
+        if (*ws) (void)hipFree(*ws);
+        *ws = nullptr; *ws_bytes = 0;
+        if (hipMalloc(ws, need) != hipSuccess) return -4;
+        *ws_bytes = need;
+    }
+    uint64_t *k_in = (uint64_t *)*ws;
+    uint64_t *k_out = (uint64_t *)((char *)*ws + key_bytes);
+    void *tmp = (char *)*ws + 2 * key_bytes;
+    const unsigned grid = (unsigned)((m + 255) / 256);
+    hipLaunchKernelGGL(build_item_keys_kernel, dim3(grid), dim3(256), 0, stream, scores, n_scores, items, m, k_in);
+    if (rocprim::radix_sort_keys(tmp, tmp_bytes, k_in, k_out, (size_t)m, 0, 64, stream) != hipSuccess) return -3;
+    hipLaunchKernelGGL(item_keys_to_ids_kernel, dim3(grid), dim3(256), 0, stream, k_out, m, out_ids);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
 struct row_offsets {

@@ -500,13 +500,17 @@ __global__ void encode_exclusions_kernel(const int64_t *indptr, const int32_t *i
 }
 
 // ------------------------------------------------------------------------------------
-// NDCG@k / Recall@k / Precision@k per user from top-K ids and the truth CSR.
+// Ranking metrics.  Per cut-off k six values: NDCG, Recall, Precision, HitRatio, F1, NCRR
+// (cornac/metrics/ranking.py:100-123, 366-386, 329-349, 291-312, 403-431, 140-180).
 // ------------------------------------------------------------------------------------
 constexpr int MAX_KS = 8;
+constexpr int NM = 6;                 // metric values per cut-off
+#define IFR_NAN __longlong_as_double(0x7ff8000000000000LL)
+
 struct MetricParams {
     const int32_t *user_ids;
     int64_t n;
-    const int32_t *topk;
+    const int32_t *topk;         // [n][K] ranked ids (-1 = no candidate)
     int K;
     int ks[MAX_KS];
     int n_k;
@@ -514,68 +518,185 @@ struct MetricParams {
     const int32_t *tr_idx;
     int64_t tr_rows;
     const double *discount;      // [IFR_MAX_TOPK] 1/log2(i+2)
-    double *per_user;            // [n][3*n_k]
+    double *per_user;            // [n][NM*n_k]
     int32_t *evaluated;
-    double *block_sums;          // [gridDim.x][3*n_k + 1]
 };
 
-__global__ __launch_bounds__(BLOCK) void metrics_kernel(MetricParams p)
+__device__ __forceinline__ bool in_sorted_row(const int32_t *idx, int64_t b, int64_t e, int id)
 {
-    __shared__ double red[BLOCK / 64][3 * MAX_KS + 1];
+    int64_t lo = b, hi = e;
+    while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (idx[mid] < id) lo = mid + 1; else hi = mid; }
+    return id >= 0 && lo < e && idx[lo] == id;
+}
+
+__device__ __forceinline__ void store_at_k(double *out, double dcg, double idcg, double crr, double icrr, int tp,
+                                           int n_pos, double tp_fp)
+{
+    const double rc = (double)tp / (double)n_pos, pr = (double)tp / tp_fp;
+    out[0] = dcg / idcg;
+    out[1] = rc;
+    out[2] = pr;
+    out[3] = tp > 0 ? 1.0 : 0.0;
+    out[4] = (pr + rc) > 0.0 ? 2.0 * (pr * rc) / (pr + rc) : 0.0;
+    out[5] = tp > 0 ? crr / icrr : 0.0;
+}
+
+// one thread per user; top-K lists of at most 32 entries (the fused kernel's output)
+__global__ __launch_bounds__(BLOCK) void metrics_topk_kernel(MetricParams p)
+{
     const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-    const int ncol = 3 * p.n_k;
-    double vals[3 * MAX_KS + 1];
+    if (i >= p.n) return;
+    const int ncol = NM * p.n_k;
+    const int u = p.user_ids[i];
+    int64_t b = 0, e = 0;
+    if (u >= 0 && u < p.tr_rows) { b = p.tr_ptr[u]; e = p.tr_ptr[u + 1]; }
+    const int n_pos = (int)(e - b);
+    if (n_pos == 0) {                       // base_method.py:258-259: user skipped
+        p.evaluated[i] = 0;
+        for (int c = 0; c < ncol; ++c) p.per_user[i * ncol + c] = IFR_NAN;
+        return;
+    }
+    p.evaluated[i] = 1;
+    uint32_t hit = 0;
+    int n_ranked = 0;
+    for (int r = 0; r < p.K; ++r) {
+        const int id = p.topk[i * p.K + r];
+        n_ranked += id >= 0 ? 1 : 0;
+        if (in_sorted_row(p.tr_idx, b, e, id)) hit |= 1u << r;
+    }
+    for (int q = 0; q < p.n_k; ++q) {
+        const int k = p.ks[q];
+        double dcg = 0.0, idcg = 0.0, crr = 0.0, icrr = 0.0;
+        int tp = 0;
+        const int trunc = min(k, n_ranked);
+        for (int r = 0; r < k; ++r) {
+            if (hit & (1u << r)) { dcg += p.discount[r]; crr += 1.0 / (double)(r + 1); ++tp; }
+            if (r < n_pos) idcg += p.discount[r];
+            if (r < n_pos && r < trunc) icrr += 1.0 / (double)(r + 1);
+        }
+        store_at_k(p.per_user + i * ncol + NM * q, dcg, idcg, crr, icrr, tp, n_pos, (double)k);
+    }
+}
+
+// Full ranked lists (k = -1 or k > 32): one workgroup per user.  Extra columns after the
+// NM*n_k block: MRR (NaN when nothing matches; ranking.py:213-223) and average precision for
+// MAP on a tie-free ranking (ranking.py:522-525).
+struct ListMetricParams {
+    const int32_t *user_ids;
+    int64_t n;
+    const int32_t *ranked;       // [n][ld]
+    int64_t ld;
+    const int32_t *n_ranked;     // [n]
+    int ks[MAX_KS];              // -1 = whole list
+    int n_k;
+    const int64_t *tr_ptr;
+    const int32_t *tr_idx;
+    int64_t tr_rows;
+    double *per_user;            // [n][NM*n_k + 2]
+    int32_t *evaluated;
+};
+
+__global__ __launch_bounds__(BLOCK) void metrics_list_kernel(ListMetricParams p)
+{
+    __shared__ double red[BLOCK / 64][2 * MAX_KS + 1];
+    __shared__ int red_i[BLOCK / 64][MAX_KS + 2];
+    __shared__ int wave_hits[BLOCK / 64];
+    const int64_t i = blockIdx.x;
+    const int ncol = NM * p.n_k + 2;
+    const int u = p.user_ids[i];
+    int64_t b = 0, e = 0;
+    if (u >= 0 && u < p.tr_rows) { b = p.tr_ptr[u]; e = p.tr_ptr[u + 1]; }
+    const int n_pos = (int)(e - b);
+    double *out = p.per_user + i * ncol;
+    if (n_pos == 0) {
+        if (threadIdx.x == 0) p.evaluated[i] = 0;
+        for (int c = threadIdx.x; c < ncol; c += BLOCK) out[c] = IFR_NAN;
+        return;
+    }
+    const int len = p.n_ranked[i];
+    const int32_t *row = p.ranked + i * p.ld;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double dcg[MAX_KS], crr[MAX_KS], ap = 0.0;
+    int tp[MAX_KS], first = 0x7fffffff, seen = 0;       // seen = hits in earlier sweeps of the list
 #pragma unroll
-    for (int c = 0; c < 3 * MAX_KS + 1; ++c) vals[c] = 0.0;
-    if (i < p.n) {
-        const int u = p.user_ids[i];
-        int64_t b = 0, e = 0;
-        if (u < p.tr_rows) { b = p.tr_ptr[u]; e = p.tr_ptr[u + 1]; }
-        const int n_pos = (int)(e - b);
-        if (n_pos == 0) {
-            p.evaluated[i] = 0;
-            for (int c = 0; c < ncol; ++c) p.per_user[i * ncol + c] = __longlong_as_double(0x7ff8000000000000LL);
-        } else {
-            p.evaluated[i] = 1;
-            // hit flags of the K ranked ids
-            uint32_t hit = 0;
-            for (int r = 0; r < p.K; ++r) {
-                const int id = p.topk[i * p.K + r];
-                int64_t lo = b, hi = e;
-                while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (p.tr_idx[mid] < id) lo = mid + 1; else hi = mid; }
-                if (id >= 0 && lo < e && p.tr_idx[lo] == id) hit |= 1u << r;
+    for (int q = 0; q < MAX_KS; ++q) { dcg[q] = 0.0; crr[q] = 0.0; tp[q] = 0; }
+    for (int base = 0; base < len; base += BLOCK) {
+        const int pos = base + threadIdx.x;
+        const bool hit = pos < len && in_sorted_row(p.tr_idx, b, e, row[pos]);
+        // 1-based index of this hit among the hits of the list, in list order (for MAP)
+        const unsigned long long bal = __ballot(hit);
+        const int before = __popcll(bal & ((1ull << lane) - 1ull));
+        if (lane == 0) wave_hits[wave] = __popcll(bal);
+        __syncthreads();
+        int prior = seen;
+        for (int w = 0; w < wave; ++w) prior += wave_hits[w];
+        int sweep = 0;
+        for (int w = 0; w < BLOCK / 64; ++w) sweep += wave_hits[w];
+        __syncthreads();
+        seen += sweep;
+        if (hit) {
+            const double disc = 1.0 / log2((double)pos + 2.0);
+            const double rr = 1.0 / (double)(pos + 1);
+            ap += (double)(prior + before + 1) * rr;
+            first = min(first, pos);
+#pragma unroll
+            for (int q = 0; q < MAX_KS; ++q) {
+                if (q < p.n_k && (p.ks[q] <= 0 || pos < p.ks[q])) { dcg[q] += disc; crr[q] += rr; ++tp[q]; }
             }
-            for (int q = 0; q < p.n_k; ++q) {
-                const int k = p.ks[q];
-                double dcg = 0.0, idcg = 0.0;
-                int tp = 0;
-                for (int r = 0; r < k; ++r) {
-                    if (hit & (1u << r)) { dcg += p.discount[r]; ++tp; }
-                    if (r < n_pos) idcg += p.discount[r];
-                }
-                const double nd = dcg / idcg, rc = (double)tp / (double)n_pos, pr = (double)tp / (double)k;
-                p.per_user[i * ncol + 3 * q + 0] = nd;
-                p.per_user[i * ncol + 3 * q + 1] = rc;
-                p.per_user[i * ncol + 3 * q + 2] = pr;
-                vals[3 * q + 0] = nd; vals[3 * q + 1] = rc; vals[3 * q + 2] = pr;
-            }
-            vals[ncol] = 1.0;
         }
     }
-    // deterministic block reduction: shuffle tree inside a wave, fixed order across waves
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int c = 0; c <= ncol; ++c) {
-        double v = vals[c];
+    // block reduction in a fixed order
 #pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
-        if (lane == 0) red[wave][c] = v;
+    for (int q = 0; q < MAX_KS; ++q) {
+        double a = dcg[q], c = crr[q];
+        int t = tp[q];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) { a += __shfl_xor(a, off); c += __shfl_xor(c, off); t += __shfl_xor(t, off); }
+        if (lane == 0) { red[wave][2 * q] = a; red[wave][2 * q + 1] = c; red_i[wave][q] = t; }
+    }
+    {
+        double a = ap;
+        int f = first;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) { a += __shfl_xor(a, off); f = min(f, __shfl_xor(f, off)); }
+        if (lane == 0) { red[wave][2 * MAX_KS] = a; red_i[wave][MAX_KS] = f; }
     }
     __syncthreads();
-    if (threadIdx.x <= ncol) {
-        double v = 0.0;
-        for (int w = 0; w < BLOCK / 64; ++w) v += red[w][threadIdx.x];
-        p.block_sums[(int64_t)blockIdx.x * (ncol + 1) + threadIdx.x] = v;
+    if (threadIdx.x == 0) {
+        p.evaluated[i] = 1;
+        double apt = 0.0;
+        int ft = 0x7fffffff;
+        for (int w = 0; w < BLOCK / 64; ++w) { apt += red[w][2 * MAX_KS]; ft = min(ft, red_i[w][MAX_KS]); }
+        for (int q = 0; q < p.n_k; ++q) {
+            double a = 0.0, c = 0.0;
+            int t = 0;
+            for (int w = 0; w < BLOCK / 64; ++w) { a += red[w][2 * q]; c += red[w][2 * q + 1]; t += red_i[w][q]; }
+            const int k = p.ks[q];
+            const int ideal = k > 0 ? min(k, n_pos) : n_pos;          // dcg_score(gt_pos, gt_pos, k)
+            const int trunc = k > 0 ? min(k, len) : len;
+            double idcg = 0.0, icrr = 0.0;
+            for (int r = 0; r < ideal; ++r) idcg += 1.0 / log2((double)r + 2.0);
+            for (int r = 0; r < min(n_pos, trunc); ++r) icrr += 1.0 / (double)(r + 1);
+            store_at_k(out + NM * q, a, idcg, c, icrr, t, n_pos, k > 0 ? (double)k : (double)len);
+        }
+        out[NM * p.n_k] = ft == 0x7fffffff ? IFR_NAN : 1.0 / (double)(ft + 1);
+        out[NM * p.n_k + 1] = apt / (double)n_pos;
     }
+}
+
+// column sums over evaluated users, two deterministic stages
+constexpr int COLSUM_ROWS = 256;
+__global__ __launch_bounds__(64) void colsum_kernel(const double *per_user, const int32_t *evaluated, int64_t n, int ncol,
+                                                    double *block_sums)
+{
+    const int c = threadIdx.x;
+    const int64_t r0 = (int64_t)blockIdx.x * COLSUM_ROWS;
+    const int64_t r1 = min(r0 + COLSUM_ROWS, n);
+    if (c > ncol) return;
+    double v = 0.0;
+    for (int64_t r = r0; r < r1; ++r)
+        if (evaluated[r]) v += (c < ncol) ? per_user[r * ncol + c] : 1.0;
+    block_sums[(int64_t)blockIdx.x * (ncol + 1) + c] = v;
 }
 
 __global__ void reduce_sums_kernel(const double *block_sums, int n_blocks, int ncol1, double *out)

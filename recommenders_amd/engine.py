@@ -10,6 +10,10 @@ import numpy as np
 from . import _lib
 
 
+METRICS_PER_K = 6      # ndcg, recall, precision, hit ratio, f1, ncrr (include/ifr.h IFR_METRICS_PER_K)
+METRIC_COLUMNS = ("ndcg", "recall", "precision", "hit", "f1", "ncrr")
+
+
 class IfrError(RuntimeError):
     """A non-zero status from libifr.so (status -> RuntimeError)."""
 
@@ -129,19 +133,45 @@ class HipScorer:
         return out_ids, out_scores
 
     def eval_topk_metrics(self, user_ids, topk_ids, ks):
-        """(per_user fp64 [n, 3*len(ks)] = ndcg/recall/precision per cut-off, evaluated int32 [n],
-        sums fp64 [3*len(ks)+1])."""
+        """(per_user fp64 [n, 6*len(ks)] = ndcg/recall/precision/hit/f1/ncrr per cut-off,
+        evaluated int32 [n], sums fp64 [6*len(ks)+1] = column sums + evaluated count)."""
         torch = _torch()
         u = self._dev_i32(user_ids)
         n = u.numel()
         ks_arr = (ctypes.c_int32 * len(ks))(*[int(k) for k in ks])
-        per_user = torch.empty((n, 3 * len(ks)), dtype=torch.float64, device=self.device)
+        ncol = METRICS_PER_K * len(ks)
+        per_user = torch.empty((n, ncol), dtype=torch.float64, device=self.device)
         evaluated = torch.empty((n,), dtype=torch.int32, device=self.device)
-        sums = torch.empty((3 * len(ks) + 1,), dtype=torch.float64, device=self.device)
+        sums = torch.empty((ncol + 1,), dtype=torch.float64, device=self.device)
         self._check(self._lib.ifr_eval_topk_metrics(
             self._h, u.data_ptr(), n, topk_ids.data_ptr(), int(topk_ids.shape[1]), ks_arr, len(ks),
             per_user.data_ptr(), evaluated.data_ptr(), sums.data_ptr(), self._stream()))
         return per_user, evaluated, sums
+
+    def eval_ranked_metrics(self, user_ids, ranked, n_ranked, ks):
+        """Metrics from full ranked lists (ks may hold -1 = whole list).  per_user has
+        6*len(ks) + 2 columns (the last two: reciprocal rank of the first hit, average precision)."""
+        torch = _torch()
+        u = self._dev_i32(user_ids)
+        n = u.numel()
+        ks_arr = (ctypes.c_int32 * len(ks))(*[int(k) for k in ks])
+        ncol = METRICS_PER_K * len(ks) + 2
+        per_user = torch.empty((n, ncol), dtype=torch.float64, device=self.device)
+        evaluated = torch.empty((n,), dtype=torch.int32, device=self.device)
+        sums = torch.empty((ncol + 1,), dtype=torch.float64, device=self.device)
+        self._check(self._lib.ifr_eval_ranked_metrics(
+            self._h, u.data_ptr(), n, ranked.data_ptr(), ranked.stride(0), n_ranked.data_ptr(), ks_arr, len(ks),
+            per_user.data_ptr(), evaluated.data_ptr(), sums.data_ptr(), self._stream()))
+        return per_user, evaluated, sums
+
+    def rank_items(self, scores_row, items):
+        """Order `items` (int32 device tensor) by scores_row[item] descending, item ascending."""
+        torch = _torch()
+        it = self._dev_i32(items)
+        out = torch.empty_like(it)
+        self._check(self._lib.ifr_rank_items(self._h, scores_row.data_ptr(), scores_row.numel(), it.data_ptr(),
+                                             it.numel(), out.data_ptr(), self._stream()))
+        return out
 
     def score_dense(self, user_ids, out=None):
         torch = _torch()

@@ -137,12 +137,21 @@ def test_metrics_vs_oracle(torch):
     np.testing.assert_array_equal(evaluated, o_ev)
     assert 0 < evaluated.sum() < len(users) or evaluated.all()
     ev = evaluated.astype(bool)
-    np.testing.assert_allclose(per_user[ev], o_met[ev][:, :9], rtol=0, atol=1e-12)
+    cols = [6 * q + c for q in range(3) for c in range(3)]            # ndcg, recall, precision of each cut-off
+    np.testing.assert_allclose(per_user[ev][:, cols], o_met[ev][:, :9], rtol=0, atol=1e-12)
     assert np.isnan(per_user[~ev]).all()
-    np.testing.assert_allclose(sums[:9], o_met[ev][:, :9].sum(0), rtol=1e-12)
-    assert sums[9] == ev.sum()
+    np.testing.assert_allclose(sums[cols], o_met[ev][:, :9].sum(0), rtol=1e-12)
+    assert sums[-1] == ev.sum()
     # aggregate (mean over evaluated users, base_method.py:302-303) within 1e-6
-    np.testing.assert_allclose(sums[:9] / sums[9], o_met[ev][:, :9].mean(0), atol=1e-6, rtol=0)
+    np.testing.assert_allclose(sums[cols] / sums[-1], o_met[ev][:, :9].mean(0), atol=1e-6, rtol=0)
+    # hit ratio / f1 / ncrr against the NumPy restatement of the reference classes
+    ids_h = ids.cpu().numpy()
+    for u in np.flatnonzero(ev)[:200]:
+        pos = w["truth_idx"][w["truth_ptr"][u]: w["truth_ptr"][u + 1]]
+        for q, k in enumerate(ks):
+            assert per_user[u, 6 * q + 3] == orc.hit_ratio(pos, ids_h[u], k)
+            assert per_user[u, 6 * q + 4] == pytest.approx(orc.f_measure(pos, ids_h[u], k), abs=1e-12)
+            assert per_user[u, 6 * q + 5] == pytest.approx(orc.ncrr(pos, ids_h[u], k), abs=1e-12)
 
 
 def test_dense_scores_match_fused_and_auc(torch):
@@ -182,6 +191,37 @@ def test_rank_full_vs_oracle(torch):
         assert (ids[u, len(cand):] == -1).all()
 
 
+def test_ranked_list_metrics_and_rank_items(torch):
+    w = _workload(11, 90, 700, 32, True, mean=30)
+    sc = _scorer(w)
+    users = np.arange(w["n_users"], dtype=np.int32)
+    dense = sc.score_dense(users)
+    ranked, n_cand = sc.rank_full(users, dense)
+    ks = [-1, 10, 50]
+    per_user, evaluated, sums = sc.eval_ranked_metrics(users, ranked, n_cand, ks)
+    per_user, evaluated = per_user.cpu().numpy(), evaluated.cpu().numpy().astype(bool)
+    rk, nc, dn = ranked.cpu().numpy(), n_cand.cpu().numpy(), dense.cpu().numpy()
+    assert evaluated.any()
+    for u in range(w["n_users"]):
+        pos = w["truth_idx"][w["truth_ptr"][u]: w["truth_ptr"][u + 1]]
+        if len(pos) == 0:
+            assert not evaluated[u] and np.isnan(per_user[u]).all()
+            continue
+        lst = rk[u, : nc[u]]
+        for q, k in enumerate(ks):
+            exp = [orc.ndcg(pos, lst, k), orc.recall(pos, lst, k), orc.precision(pos, lst, k),
+                   orc.hit_ratio(pos, lst, k), orc.f_measure(pos, lst, k), orc.ncrr(pos, lst, k)]
+            np.testing.assert_allclose(per_user[u, 6 * q: 6 * q + 6], exp, rtol=0, atol=1e-12)
+        assert per_user[u, 18] == pytest.approx(orc.mrr(pos, lst), abs=1e-15)
+        assert per_user[u, 19] == pytest.approx(orc.average_precision(lst, dn[u][lst].astype(np.float64), pos), abs=1e-12)
+    s = sums.cpu().numpy()
+    np.testing.assert_allclose(s[:-1], per_user[evaluated].sum(0), rtol=1e-12)
+    # arbitrary candidate list of one user (Recommender.rank with item_indices)
+    cand = np.random.default_rng(1).permutation(w["n_items"])[:333].astype(np.int32)
+    got = sc.rank_items(dense[7], torch.from_numpy(cand).cuda()).cpu().numpy()
+    np.testing.assert_array_equal(got, orc.canonical_rank(cand, dn[7][cand]))
+
+
 @pytest.mark.parametrize("model", ["bpr", "mf", "wmf"])
 def test_golden_reference_fixture(torch, toy, model):
     """Per-user NDCG/Recall/Precision@K from the HIP path against the values the reference
@@ -216,7 +256,7 @@ def test_golden_reference_fixture(torch, toy, model):
     per_user = per_user.cpu().numpy()
     assert evaluated.cpu().numpy().all()
     names = [str(x) for x in d["metric_names"]]
-    col = {"ndcg@10": 0, "recall@10": 1, "precision@10": 2, "ndcg@5": 3, "recall@20": 7}
+    col = {"ndcg@10": 0, "recall@10": 1, "precision@10": 2, "ndcg@5": 6, "recall@20": 13}
     ref = d[f"{model}__per_user"]
     ref_head, ref_hs = d[f"{model}__ranked_head"], d[f"{model}__ranked_head_scores"]
     ids = ids.cpu().numpy()
