@@ -1,0 +1,272 @@
+"""ranking_eval / cache_rankings with the reference's signatures
+(cornac/eval_methods/base_method.py:143-305), executed as a few batched HIP launches instead of
+one Python iteration per user.
+
+Host side (this file): turn the train / validation / test CSR matrices into the two CSRs the
+kernels read (exclusions and truth, SURVEY.md Appendix B rules 1-3), pick the launch path from
+the metric list, shard the test users across ranks when torch.distributed is initialised, and
+assemble the reference's return value `(avg_results, user_results)`.
+"""
+from collections.abc import Mapping
+
+import numpy as np
+import scipy.sparse as sp
+
+from . import dist as ifr_dist
+from .engine import METRIC_COLUMNS, METRICS_PER_K
+from .metrics import metric_kind
+
+MAX_FUSED_K = 32
+
+
+# --------------------------------------------------------------------------- CSR preparation
+def _positive_csr(mat, thr, n_rows, n_cols):
+    """Rows of `mat` restricted to rating >= thr and item < n_cols, as a boolean CSR with
+    n_rows rows (rows beyond mat.shape[0] are empty: base_method.py:266-270)."""
+    mat = sp.csr_matrix(mat)
+    keep = mat.data >= thr
+    coo_rows = np.repeat(np.arange(mat.shape[0]), np.diff(mat.indptr))[keep]
+    cols = mat.indices[keep]
+    ok = (cols < n_cols) & (coo_rows < n_rows)
+    out = sp.csr_matrix((np.ones(int(ok.sum()), np.int8), (coo_rows[ok], cols[ok])), shape=(n_rows, n_cols))
+    out.sum_duplicates()
+    out.sort_indices()
+    return out
+
+
+def build_eval_csrs(train_mat, test_mat, val_mat, rating_threshold, n_items, n_rows):
+    """-> (truth CSR, exclusion CSR, evaluated-candidate users) per base_method.py:246-283.
+
+    truth[u]     = test items rated >= threshold, clipped to [0, n_items)            (gt_pos)
+    exclusion[u] = (train U validation items rated >= threshold) minus truth[u]     (not ranked)
+    has_pos[u]   = user has a test item rated >= threshold *before* clipping (:257-259)."""
+    test_mat = sp.csr_matrix(test_mat)
+    keep = test_mat.data >= rating_threshold
+    rows = np.repeat(np.arange(test_mat.shape[0]), np.diff(test_mat.indptr))[keep]
+    has_pos = np.zeros(n_rows, bool)
+    has_pos[rows[rows < n_rows]] = True
+    truth = _positive_csr(test_mat, rating_threshold, n_rows, n_items)
+    excl = _positive_csr(train_mat, rating_threshold, n_rows, n_items)
+    if val_mat is not None:
+        excl = excl + _positive_csr(val_mat, rating_threshold, n_rows, n_items)
+    excl = excl - excl.multiply(truth)              # test positives stay candidates (mask sum = 1)
+    excl.eliminate_zeros()
+    excl.sort_indices()
+    return truth, excl, has_pos
+
+
+# --------------------------------------------------------------------------- lazy result caches
+class LazyRankCache(Mapping):
+    """Dict-like view that materialises `model.ranked_items[u]` / `item_scores[u]` /
+    `item_scores_mapped_indices[u]` on first access.  The reference stores three full-length
+    arrays per evaluated user (recommender.py:655-659); at 10M x 1M that is ~200 TB
+    (SURVEY.md section 7), so the batched path keeps only the recipe."""
+
+    def __init__(self, owner, field, users, explicit=None):
+        self._owner, self._field = owner, field
+        self._users = users                      # sorted int array of users with a lazy entry
+        self._explicit = {} if explicit is None else explicit
+
+    def _lazy_has(self, u):
+        i = np.searchsorted(self._users, u)
+        return i < len(self._users) and self._users[i] == u
+
+    def __contains__(self, u):
+        return u in self._explicit or self._lazy_has(u)
+
+    def __getitem__(self, u):
+        if u not in self._explicit:
+            if not self._lazy_has(u):
+                raise KeyError(u)
+            self._owner._materialise_cached_user(int(u))
+        return self._explicit[u]
+
+    def __setitem__(self, u, value):
+        self._explicit[u] = value
+
+    def __iter__(self):
+        seen = set(self._explicit)
+        yield from self._explicit
+        for u in self._users:
+            if int(u) not in seen:
+                yield int(u)
+
+    def __len__(self):
+        return len(set(self._explicit) | set(int(u) for u in self._users))
+
+    def __reduce__(self):                         # pickles as the plain dict the reference writes
+        return (dict, (dict(self.items()),))
+
+
+class _CacheOwner:
+    """Holds what is needed to rebuild one user's full ranking exactly as the batched
+    evaluation saw it (same candidate set)."""
+
+    def __init__(self, model, excl, n_items, users):
+        self.model, self.excl, self.n_items, self.users = model, excl, n_items, users
+
+    def _materialise_cached_user(self, u):
+        m = self.model
+        row = self.excl[u] if u < self.excl.shape[0] else None
+        mask = np.ones(self.n_items, bool)
+        if row is not None:
+            mask[row.indices] = False
+        cand = np.nonzero(mask)[0]
+        # model.rank refills the three caches itself (recommender.py:655-659)
+        ranked_items, item_scores = m.rank(user_idx=u, item_indices=cand, k=-1)
+        return ranked_items, item_scores
+
+
+def cache_rankings(model, user_idx, item_indices, k=-1):
+    """base_method.py:143-182."""
+    if not hasattr(model, "ranked_items"):
+        model.ranked_items = {}
+    if not hasattr(model, "item_scores"):
+        model.item_scores = {}
+    if user_idx in model.ranked_items and user_idx in model.item_scores:
+        return model.ranked_items[user_idx], model.item_scores[user_idx]
+    if not getattr(model, "is_fitted", False):
+        raise RuntimeError("Model is not fitted. Please call `model.fit()` before ranking.")
+    item_rank, item_scores = model.rank(user_idx=user_idx, item_indices=item_indices, k=k)
+    model.ranked_items[user_idx] = item_rank
+    model.item_scores[user_idx] = item_scores
+    return item_rank, item_scores
+
+
+# --------------------------------------------------------------------------- metric plan
+def plan_metrics(metrics):
+    """-> (specs, fused_ks, list_ks, need_auc, need_list).  specs[i] = (kind, k) of metrics[i]."""
+    specs = []
+    for mt in metrics:
+        kind = metric_kind(mt)
+        k = getattr(mt, "k", -1)
+        if hasattr(k, "__len__"):
+            raise ValueError("list-valued k must be expanded by the caller (BaseMethod.organize_metrics does)")
+        specs.append((kind, int(k)))
+    per_k = [(kind, k) for kind, k in specs if kind in METRIC_COLUMNS]
+    need_list = any(kind in ("mrr", "map") for kind, _ in specs) or any(k <= 0 or k > MAX_FUSED_K for _, k in per_k)
+    need_auc = any(kind == "auc" for kind, _ in specs)
+    ks = sorted({k for _, k in per_k}, key=lambda v: (v <= 0, v))
+    return specs, ks, need_auc, need_list
+
+
+# --------------------------------------------------------------------------- ranking_eval
+def ranking_eval(model, metrics, train_set, test_set, val_set=None, rating_threshold=1.0, exclude_unknowns=True,
+                 verbose=False, *, batch_pairs=1 << 28, distributed="auto", gather_user_results=True, _engine=None):
+    """Evaluate `model` on ranking metrics: reference signature and return value
+    (base_method.py:185-305).  Keyword-only extras: `batch_pairs` bounds users x items of a dense
+    score batch (AUC / k = -1 paths), `distributed` shards the test users over the ranks of an
+    initialised torch.distributed group and all-reduces the metric sums (one RCCL/gloo
+    all-reduce), `gather_user_results` also gathers the per-user values to every rank."""
+    if len(metrics) == 0:
+        return [], []
+    import torch
+    specs, ks, need_auc, need_list = plan_metrics(metrics)
+    if not getattr(model, "is_fitted", False):
+        raise RuntimeError("Model is not fitted. Please call `model.fit()` before ranking.")
+    if _engine is None and not hasattr(model, "_hip_engine"):
+        raise TypeError("ranking_eval needs a model with the HIP scoring path (recommenders_amd.models.HipScoringMixin); "
+                        "there is no CPU fallback")
+    eng = model._hip_engine() if _engine is None else _engine
+
+    n_items = train_set.num_items if exclude_unknowns else test_set.num_items
+    if n_items != eng.n_items:
+        raise NotImplementedError(
+            f"ranking over {n_items} items but the model scores {eng.n_items}: exclude_unknowns=False with items "
+            "unknown to the model (min-score padding, recommender.py:631-635) is served by model.rank(), not by the "
+            "batched path yet")
+    test_users = np.unique(np.asarray(test_set.uir_tuple[0]).astype(np.int64))
+    n_rows = int(test_users.max()) + 1 if len(test_users) else 0
+    truth, excl, has_pos = build_eval_csrs(train_set.csr_matrix, test_set.csr_matrix,
+                                           None if val_set is None else val_set.csr_matrix,
+                                           rating_threshold, n_items, n_rows)
+    # reference quirk kept: users already in the model's caches are NOT re-ranked
+    # (base_method.py:166-167), so their earlier candidate set (exclusion rows) stays in force
+    prev = getattr(model, "_hip_cache_owner", None)
+    if prev is not None and prev.n_items == n_items and len(prev.users):
+        reuse = prev.users[prev.users < n_rows]
+        if len(reuse):
+            keep = np.ones(n_rows, bool)
+            keep[reuse] = False
+            old = prev.excl[:n_rows] if prev.excl.shape[0] >= n_rows else sp.vstack(
+                [prev.excl, sp.csr_matrix((n_rows - prev.excl.shape[0], n_items), dtype=prev.excl.dtype)]).tocsr()
+            excl = (sp.diags(keep.astype(np.int8)) @ excl + sp.diags((~keep).astype(np.int8)) @ old).tocsr()
+            excl.sort_indices()
+    users = test_users[has_pos[test_users]]                      # base_method.py:258-259
+    eng.set_exclusion_csr(excl.indptr.astype(np.int64), excl.indices.astype(np.int32))
+    eng.set_truth_csr(truth.indptr.astype(np.int64), truth.indices.astype(np.int32))
+
+    # ---- shard users over ranks
+    world, rank = ifr_dist.world_and_rank(distributed)
+    lo, hi = ifr_dist.shard_range(len(users), rank, world)
+    my_users = users[lo:hi]
+    # Users the model does not know keep their own index: the engine holds an all-zero factor row
+    # for each of them (HipScoringMixin._hip_engine), which reproduces both "the user term is
+    # dropped" (MF, recom_mf.py:277-280) and "constant default score, every candidate ties"
+    # (ScoreException, recommender.py:626-627: same order, same metrics).
+    if len(my_users) and int(my_users.max()) >= eng.n_users:
+        raise ValueError(f"test user index {int(my_users.max())} beyond the {eng.n_users} rows the engine holds")
+    n = len(my_users)
+    values = np.full((n, len(specs)), np.nan)
+    col_of = {}
+    if n:
+        dev_users = torch.as_tensor(my_users.astype(np.int32), device=eng.device)
+        if not need_list and ks:
+            kmax = max(ks)
+            ids, _ = eng.rank_topk(dev_users, kmax)
+            per_user, _, _ = eng.eval_topk_metrics(dev_users, ids, ks)
+            per_user = per_user.cpu().numpy()
+            for qi, k in enumerate(ks):
+                for ci, name in enumerate(METRIC_COLUMNS):
+                    col_of[(name, k)] = per_user[:, METRICS_PER_K * qi + ci]
+        if need_list or need_auc:
+            step = max(1, int(batch_pairs // max(1, n_items)))
+            lst_ks = ks if ks else [-1]
+            per_list = np.empty((n, METRICS_PER_K * len(lst_ks) + 2)) if need_list else None
+            auc = np.empty(n) if need_auc else None
+            for b in range(0, n, step):
+                bu = dev_users[b:b + step]
+                dense = eng.score_dense(bu)
+                if need_auc:
+                    auc[b:b + step] = eng.auc_dense(bu, dense).cpu().numpy()
+                if need_list:
+                    ranked, n_cand = eng.rank_full(bu, dense)
+                    pl, _, _ = eng.eval_ranked_metrics(bu, ranked, n_cand, lst_ks)
+                    per_list[b:b + step] = pl.cpu().numpy()
+            if need_list:
+                for qi, k in enumerate(lst_ks):
+                    for ci, name in enumerate(METRIC_COLUMNS):
+                        col_of[(name, k)] = per_list[:, METRICS_PER_K * qi + ci]
+                col_of[("mrr", -1)] = per_list[:, -2]
+                col_of[("map", -1)] = per_list[:, -1]
+            if need_auc:
+                col_of[("auc", -1)] = auc
+        for i, (kind, k) in enumerate(specs):
+            key = (kind, k) if kind in METRIC_COLUMNS else (kind, -1)
+            values[:, i] = col_of[key]
+        if any(kind == "mrr" for kind, _ in specs):
+            i = [kind for kind, _ in specs].index("mrr")
+            if np.isnan(values[:, i]).any():
+                raise ValueError("No matched between ground-truth items and recommendations")   # ranking.py:215-218
+
+    # ---- aggregate: sums + count, one all-reduce across ranks (base_method.py:302-303)
+    sums = np.concatenate([values.sum(axis=0), [float(n)]]) if n else np.zeros(len(specs) + 1)
+    sums = ifr_dist.all_reduce_sums(sums, world, getattr(eng, "device", None))
+    if sums[-1] == 0:
+        raise ZeroDivisionError("division by zero")                  # len(user_results[i]) == 0 in the reference
+    avg_results = [float(sums[i] / sums[-1]) for i in range(len(specs))]
+    all_users, all_values = my_users, values
+    if world > 1 and gather_user_results:
+        all_users, all_values = ifr_dist.gather_rows(my_users, values, world)
+    user_results = [dict(zip(all_users.tolist(), all_values[:, i].tolist())) for i in range(len(specs))]
+
+    # ---- result caches: lazy, same candidate sets as this evaluation
+    if hasattr(model, "rank"):
+        old_users = prev.users if prev is not None else np.zeros(0, np.int64)
+        owner = _CacheOwner(model, excl, n_items, np.union1d(old_users, users))
+        model._hip_cache_owner = owner
+        for field in ("ranked_items", "item_scores", "item_scores_mapped_indices"):
+            cur = getattr(model, field, {})
+            explicit = cur._explicit if isinstance(cur, LazyRankCache) else cur
+            setattr(model, field, LazyRankCache(owner, field, owner.users, explicit))
+    return avg_results, user_results

@@ -1,0 +1,325 @@
+"""Reference-shaped model facades over the HIP engine.
+
+`HipScoringMixin` re-implements `Recommender.score` / `Recommender.rank`
+(cornac/models/recommender.py:480-498, 533-661) and adds the batched `rank_batch`, keeping the
+reference's signatures, return types, exceptions and the three result caches
+(`ranked_items`, `item_scores`, `item_scores_mapped_indices`, recommender.py:160-168, 655-659).
+It can be mixed into the reference's own classes or used through the
+stand-alone `BPR` / `MF` / `WMF` classes below, which take already-trained parameters
+(`init_params=...`, like the reference's `trainable=False` usage; training is out of scope).
+
+There is no CPU fallback: every score and every ordering comes from libifr.so.  The only host
+work is bookkeeping (id maps, candidate arrays, the all-ties case of an unknown user, whose
+"ranking" is the candidate list in ascending item index).
+"""
+import numpy as np
+
+from .exception import ScoreException
+
+
+class RecommenderBase:
+    """The subset of cornac.models.Recommender (recommender.py:84-170, 362-464, 500-502, 708-756)
+    that the hot path and its callers touch."""
+
+    def __init__(self, name, trainable=True, verbose=False, **kwargs):
+        self.name = name
+        self.trainable = trainable
+        self.verbose = verbose
+        self.is_fitted = False
+        self.num_users = None
+        self.num_items = None
+        self.uid_map = None
+        self.iid_map = None
+        self.max_rating = None
+        self.min_rating = None
+        self.global_mean = None
+        self.article_pool = None
+        for key, value in kwargs.items():
+            setattr(self, key, value)
+        self.ranked_items = {}
+        self.item_scores = {}
+        self.item_scores_mapped_indices = {}
+
+    @property
+    def total_users(self):
+        return len(self.uid_map) if self.uid_map is not None else self.num_users
+
+    @property
+    def total_items(self):
+        return len(self.iid_map) if self.iid_map is not None else self.num_items
+
+    @property
+    def user_ids(self):
+        return list(self.uid_map.keys())
+
+    @property
+    def item_ids(self):
+        return list(self.iid_map.keys())
+
+    def fit(self, train_set, val_set=None):
+        """recommender.py:362-402: bookkeeping only."""
+        self.num_users = train_set.num_users
+        self.num_items = train_set.num_items
+        self.uid_map = train_set.uid_map
+        self.iid_map = train_set.iid_map
+        self.min_rating = train_set.min_rating
+        self.max_rating = train_set.max_rating
+        self.global_mean = train_set.global_mean
+        self.train_set = train_set
+        self.val_set = val_set
+        self.is_fitted = True
+        return self
+
+    def knows_user(self, user_idx):
+        return user_idx is not None and user_idx >= 0 and user_idx < self.num_users
+
+    def knows_item(self, item_idx):
+        return item_idx is not None and item_idx >= 0 and item_idx < self.num_items
+
+    def is_unknown_user(self, user_idx):
+        return not self.knows_user(user_idx)
+
+    def is_unknown_item(self, item_idx):
+        return not self.knows_item(item_idx)
+
+    def transform(self, test_set):
+        pass
+
+    def default_score(self):
+        return self.global_mean
+
+    def recommend(self, user_id, k=-1, remove_seen=False, train_set=None):
+        """recommender.py:708-756."""
+        user_idx = self.uid_map.get(user_id, -1)
+        if user_idx == -1:
+            raise ValueError(f"{user_id} is unknown to the model.")
+        if k < -1 or k > self.total_items:
+            raise ValueError(f"k={k} is invalid, there are {self.total_users} users in total.")
+        item_indices = np.arange(self.total_items)
+        if remove_seen:
+            seen_mask = np.zeros(len(item_indices), dtype="bool")
+            if train_set is None:
+                raise ValueError("train_set must be provided to remove seen items.")
+            if user_idx < train_set.csr_matrix.shape[0]:
+                seen_mask[train_set.csr_matrix.getrow(user_idx).indices] = True
+                item_indices = item_indices[~seen_mask]
+        item_rank, _ = self.rank(user_idx, item_indices)
+        if k != -1:
+            item_rank = item_rank[:k]
+        item_ids = self.item_ids
+        return [item_ids[i] for i in item_rank]
+
+
+class HipScoringMixin:
+    """score / rank / rank_batch on the HIP engine for dot-product models.
+
+    A concrete class supplies `_hip_factor_params() -> (U, V, ubase, ibase)` (fp32 arrays:
+    score(u, i) = (ibase[i] + ubase[u]) + <U[u], V[i]>) and `_hip_user_row(user_idx)`: the row of
+    U to use, -1 for "the model raises ScoreException for this user", or the index of the
+    all-zero row appended after U for "the user term is dropped" (MF, recom_mf.py:277-280)."""
+
+    hip_device = 0
+    score_dtype = np.float32
+
+    # ---- engine life cycle
+    def _hip_engine(self):
+        eng = getattr(self, "_hip", None)
+        if eng is None:
+            from .engine import HipScorer
+            U, V, ubase, ibase = self._hip_factor_params()
+            U = np.ascontiguousarray(U, np.float32)
+            # all-zero rows for every user index the model has no factors for (up to total_users)
+            # plus one spare: users whose user term is dropped, or who cannot be scored, map there
+            n_ext = max(int(self.total_users or 0), U.shape[0]) + 1
+            Ue = np.zeros((n_ext, U.shape[1]), np.float32)
+            Ue[: U.shape[0]] = U
+            ube = None
+            if ubase is not None:
+                ube = np.zeros(n_ext, np.float32)
+                ube[: len(ubase)] = np.asarray(ubase, np.float32)
+            if ube is None and ibase is not None:
+                ube = np.zeros(len(Ue), np.float32)
+            eng = HipScorer(self.hip_device)
+            eng.set_factors(Ue, np.ascontiguousarray(V, np.float32), ube,
+                            None if ibase is None else np.ascontiguousarray(ibase, np.float32))
+            self._hip = eng
+            self._hip_zero_row = n_ext - 1
+        return eng
+
+    def hip_invalidate(self):
+        """Drop the device copy (call after the parameters change)."""
+        eng = getattr(self, "_hip", None)
+        if eng is not None:
+            eng.close()
+        self._hip = None
+
+    # ---- Recommender.score
+    def score(self, user_idx, item_idx=None, **kwargs):
+        row = self._hip_user_row(user_idx)
+        if row < 0:
+            raise ScoreException("Can't make score prediction for user %d" % user_idx)
+        if item_idx is not None and self._hip_item_must_be_known and self.is_unknown_item(item_idx):
+            raise ScoreException("Can't make score prediction for item %d" % item_idx)
+        eng = self._hip_engine()
+        dense = eng.score_dense(np.asarray([row], np.int32))[0]
+        if item_idx is None:
+            return dense.cpu().numpy().astype(self.score_dtype, copy=False)
+        return self.score_dtype(dense[int(item_idx)].item())
+
+    _hip_item_must_be_known = True
+
+    # ---- Recommender.rank
+    def rank(self, user_idx, item_indices=None, k=-1, **kwargs):
+        """recommender.py:533-661 (the article_pool branch is the caller's: it only pre-selects
+        item_indices).  Returns (item_rank int64, item_scores aligned with item_indices)."""
+        import torch
+        eng = self._hip_engine()
+        total_items = self.total_items
+        row = self._hip_user_row(user_idx)
+        if row < 0:
+            # ScoreException -> constant default_score (recommender.py:626-627): every candidate
+            # ties, the canonical order is ascending item index
+            all_scores = np.ones(total_items) * self.default_score()
+            cand = np.arange(self.num_items) if item_indices is None else np.asarray(item_indices)
+            item_scores = all_scores[cand]
+            ranked = np.sort(cand, kind="stable")
+        else:
+            known = eng.score_dense(np.asarray([row], np.int32))[0]                 # device fp32 [num_items]
+            if known.numel() != total_items:
+                # unknown items get the minimum known score (recommender.py:631-635)
+                pad = torch.full((total_items - known.numel(),), known.min().item(), dtype=known.dtype,
+                                 device=known.device)
+                known = torch.cat([known, pad])
+            cand = np.arange(self.num_items) if item_indices is None else np.asarray(item_indices)
+            cand_dev = torch.as_tensor(cand.astype(np.int32), device=known.device)
+            ranked = eng.rank_items(known, cand_dev).cpu().numpy().astype(cand.dtype if cand.dtype.kind == "i" else np.int64)
+            item_scores = known[cand_dev.long()].cpu().numpy().astype(self.score_dtype, copy=False)
+        if k != -1 and k > len(cand):
+            raise ValueError("kth(=%d) out of bounds (%d)" % (k, len(cand)))    # np.argpartition's error
+        self.ranked_items[user_idx] = ranked
+        self.item_scores[user_idx] = item_scores
+        self.item_scores_mapped_indices[user_idx] = cand
+        return ranked, item_scores
+
+    # ---- batched entry point (the shape of BaseANN.knn_query / recommend_batch,
+    # cornac/models/ann/recom_ann_base.py:91-98, 182-235)
+    def rank_batch(self, user_indices, k, exclude_csr=None):
+        """Top-k (ids int32 [n,k], scores fp32 [n,k]) for many users in one fused launch.
+        exclude_csr: optional scipy CSR / (indptr, indices) of items to leave out per user."""
+        eng = self._hip_engine()
+        users = np.asarray(user_indices)
+        rows = np.asarray([self._hip_user_row(int(u)) for u in users], np.int64)
+        if (rows < 0).any():
+            raise ScoreException("rank_batch: the model cannot score user %d" % int(users[rows < 0][0]))
+        if exclude_csr is not None:
+            ptr, idx = (exclude_csr.indptr, exclude_csr.indices) if hasattr(exclude_csr, "indptr") else exclude_csr
+            if (rows != users).any():
+                raise ValueError("rank_batch: exclusions need user rows that exist in the model")
+            eng.set_exclusion_csr(np.asarray(ptr, np.int64), np.asarray(idx, np.int32))
+        ids, scores = eng.rank_topk(rows.astype(np.int32), int(k))
+        return ids.cpu().numpy(), scores.cpu().numpy()
+
+
+class BPR(HipScoringMixin, RecommenderBase):
+    """cornac.models.BPR scoring (cornac/models/bpr/recom_bpr.pyx:272-297): s = Bi + V.U[u].
+    init_params: {'U': [total_users,k], 'V': [total_items,k], 'Bi': [total_items]}."""
+
+    def __init__(self, name="BPR", k=10, use_bias=True, trainable=False, verbose=False, init_params=None, seed=None,
+                 **kwargs):
+        RecommenderBase.__init__(self, name=name, trainable=trainable, verbose=verbose)
+        if trainable:
+            raise NotImplementedError("training is outside the hot path: fit the reference model and pass init_params")
+        self.k, self.use_bias, self.seed = int(k), use_bias, seed
+        self.init_params = {} if init_params is None else init_params
+        self.u_factors = self.init_params.get("U")
+        self.i_factors = self.init_params.get("V")
+        self.i_biases = self.init_params.get("Bi")
+
+    def _hip_factor_params(self):
+        bi = self.i_biases if (self.i_biases is not None and self.use_bias) else np.zeros(len(self.i_factors), np.float32)
+        return self.u_factors, self.i_factors, None, bi
+
+    _hip_item_must_be_known = False     # BPR.score never raises (recom_bpr.pyx:290-297)
+
+    def _hip_user_row(self, user_idx):
+        return int(user_idx)            # factors are allocated for total_users (recom_bpr.pyx:146-151)
+
+
+class MF(HipScoringMixin, RecommenderBase):
+    """cornac.models.MF scoring (cornac/models/mf/recom_mf.py:254-286):
+    s = ((mu + Bi) + Bu[u]) + V.U[u]; an unknown user keeps only mu + Bi."""
+
+    def __init__(self, name="MF", k=10, use_bias=True, trainable=False, verbose=False, init_params=None, seed=None,
+                 **kwargs):
+        RecommenderBase.__init__(self, name=name, trainable=trainable, verbose=verbose)
+        if trainable:
+            raise NotImplementedError("training is outside the hot path: fit the reference model and pass init_params")
+        self.k, self.use_bias, self.seed = k, use_bias, seed
+        self.init_params = {} if init_params is None else init_params
+        self.u_factors = self.init_params.get("U")
+        self.i_factors = self.init_params.get("V")
+        self.u_biases = self.init_params.get("Bu")
+        self.i_biases = self.init_params.get("Bi")
+        self._mu_override = self.init_params.get("mu")
+
+    def fit(self, train_set, val_set=None):
+        RecommenderBase.fit(self, train_set, val_set)
+        mu = self.global_mean if self._mu_override is None else self._mu_override
+        self.global_mean = np.float32(mu if self.use_bias else 0.0)          # recom_mf.py:156
+        return self
+
+    def _hip_factor_params(self):
+        nu, ni = self.u_factors.shape[0], self.i_factors.shape[0]
+        bu = np.zeros(nu, np.float32) if self.u_biases is None else np.asarray(self.u_biases, np.float32)
+        bi = np.zeros(ni, np.float32) if self.i_biases is None else np.asarray(self.i_biases, np.float32)
+        ibase = (np.float32(self.global_mean) + bi).astype(np.float32)       # fl(mu + Bi), recom_mf.py:276
+        return self.u_factors, self.i_factors, bu, ibase
+
+    def _hip_user_row(self, user_idx):
+        if self.knows_user(user_idx):
+            return int(user_idx)
+        self._hip_engine()
+        return int(user_idx) if self.num_users <= user_idx < self._hip_zero_row else self._hip_zero_row
+
+
+class WMF(HipScoringMixin, RecommenderBase):
+    """cornac.models.WMF scoring (cornac/models/wmf/recom_wmf.py:213-239): s = V.U[u];
+    unknown users / items raise ScoreException."""
+
+    def __init__(self, name="WMF", k=200, trainable=False, verbose=False, init_params=None, seed=None, **kwargs):
+        RecommenderBase.__init__(self, name=name, trainable=trainable, verbose=verbose)
+        if trainable:
+            raise NotImplementedError("training is outside the hot path: fit the reference model and pass init_params")
+        self.k, self.seed = k, seed
+        self.init_params = {} if init_params is None else init_params
+        self.U = self.init_params.get("U")
+        self.V = self.init_params.get("V")
+
+    def _hip_factor_params(self):
+        return self.U, self.V, None, None
+
+    def _hip_user_row(self, user_idx):
+        return int(user_idx) if self.knows_user(user_idx) else -1
+
+
+def wrap_reference_model(model, device=0):
+    """Give a fitted reference model (cornac.models.BPR / MF / WMF instance) the HIP scoring path
+    without touching its class: returns a facade that shares its parameter arrays and fit
+    bookkeeping.  INTEGRATION.md shows the subclassing alternative."""
+    name = type(model).__name__
+    if name == "BPR":
+        out = BPR(name=model.name, k=model.k, use_bias=model.use_bias,
+                  init_params={"U": model.u_factors, "V": model.i_factors, "Bi": model.i_biases})
+    elif name == "MF":
+        out = MF(name=model.name, k=model.k, use_bias=model.use_bias,
+                 init_params={"U": model.u_factors, "V": model.i_factors, "Bu": model.u_biases, "Bi": model.i_biases,
+                              "mu": model.global_mean})
+    elif name == "WMF":
+        out = WMF(name=model.name, k=model.k, init_params={"U": model.U, "V": model.V})
+    else:
+        raise TypeError(f"no HIP scoring facade for {name}")
+    for attr in ("num_users", "num_items", "uid_map", "iid_map", "min_rating", "max_rating", "global_mean",
+                 "is_fitted"):
+        setattr(out, attr, getattr(model, attr))
+    out.hip_device = device
+    return out

@@ -1,0 +1,116 @@
+"""OracleEngine: a CPU stand-in with HipScorer's method surface, computing with the oracle.
+
+TEST INFRASTRUCTURE.  It lets the `-m "not gpu"` suite exercise the host logic of
+recommenders_amd.eval (CSR preparation, metric planning, sharding, all-reduce, result
+assembly, caches) without a GPU.  It is never importable from the product package."""
+import numpy as np
+import torch
+
+from oracle import oracle as orc
+
+METRICS_PER_K = 6
+
+
+class OracleEngine:
+    def __init__(self, U, V, ubase=None, ibase=None):
+        self.U, self.V = np.asarray(U, np.float32), np.asarray(V, np.float32)
+        self.ubase = None if ubase is None else np.asarray(ubase, np.float32)
+        self.ibase = None if ibase is None else np.asarray(ibase, np.float32)
+        if self.ibase is None and self.ubase is not None:
+            self.ibase = np.zeros(len(self.V), np.float32)
+        self.n_users, self.n_items, self.k = len(self.U), len(self.V), self.U.shape[1]
+        self.device = torch.device("cpu")
+        self.ex = (np.zeros(1, np.int64), np.zeros(0, np.int32))
+        self.tr = (np.zeros(1, np.int64), np.zeros(0, np.int32))
+
+    def set_exclusion_csr(self, indptr, indices):
+        self.ex = (np.asarray(indptr, np.int64), np.asarray(indices, np.int32))
+
+    def set_truth_csr(self, indptr, indices):
+        self.tr = (np.asarray(indptr, np.int64), np.asarray(indices, np.int32))
+
+    def _row(self, csr, u):
+        ptr, idx = csr
+        return idx[ptr[u]: ptr[u + 1]] if u + 1 < len(ptr) else idx[:0]
+
+    def _scores(self, u):
+        ub = 0.0 if self.ubase is None else float(self.ubase[u])
+        return orc.c_score_factor(self.U[u], self.V, self.ibase, ub, None)
+
+    def score_dense(self, user_ids):
+        return torch.from_numpy(np.stack([self._scores(int(u)) for u in np.asarray(user_ids)]))
+
+    def rank_topk(self, user_ids, K):
+        users = np.asarray(user_ids)
+        ids = np.full((len(users), K), -1, np.int32)
+        sc = np.full((len(users), K), -np.inf, np.float32)
+        for r, u in enumerate(users):
+            s = self._scores(int(u))
+            cand = np.setdiff1d(np.arange(self.n_items), self._row(self.ex, int(u)))
+            head = orc.canonical_rank(cand, s[cand], K)
+            ids[r, : len(head)] = head
+            sc[r, : len(head)] = s[head]
+        return torch.from_numpy(ids), torch.from_numpy(sc)
+
+    def rank_full(self, user_ids, dense):
+        users = np.asarray(user_ids)
+        out = np.full((len(users), self.n_items), -1, np.int32)
+        n_cand = np.zeros(len(users), np.int32)
+        d = dense.numpy()
+        for r, u in enumerate(users):
+            cand = np.setdiff1d(np.arange(self.n_items), self._row(self.ex, int(u)))
+            out[r, : len(cand)] = orc.canonical_rank(cand, d[r][cand])
+            n_cand[r] = len(cand)
+        return torch.from_numpy(out), torch.from_numpy(n_cand)
+
+    def _six(self, pos, lst, k):
+        return [orc.ndcg(pos, lst, k), orc.recall(pos, lst, k), orc.precision(pos, lst, k),
+                orc.hit_ratio(pos, lst, k), orc.f_measure(pos, lst, k), orc.ncrr(pos, lst, k)]
+
+    def eval_topk_metrics(self, user_ids, topk_ids, ks):
+        users, ids = np.asarray(user_ids), topk_ids.numpy()
+        out = np.full((len(users), METRICS_PER_K * len(ks)), np.nan)
+        ev = np.zeros(len(users), np.int32)
+        for r, u in enumerate(users):
+            pos = self._row(self.tr, int(u))
+            if len(pos) == 0:
+                continue
+            ev[r] = 1
+            lst = ids[r][ids[r] >= 0]
+            for q, k in enumerate(ks):
+                out[r, 6 * q: 6 * q + 6] = self._six(pos, lst, k)
+        sums = np.concatenate([out[ev == 1].sum(0), [ev.sum()]])
+        return torch.from_numpy(out), torch.from_numpy(ev), torch.from_numpy(sums)
+
+    def eval_ranked_metrics(self, user_ids, ranked, n_ranked, ks):
+        users, rk, nr = np.asarray(user_ids), ranked.numpy(), n_ranked.numpy()
+        out = np.full((len(users), METRICS_PER_K * len(ks) + 2), np.nan)
+        ev = np.zeros(len(users), np.int32)
+        for r, u in enumerate(users):
+            pos = self._row(self.tr, int(u))
+            if len(pos) == 0:
+                continue
+            ev[r] = 1
+            lst = rk[r, : nr[r]]
+            for q, k in enumerate(ks):
+                out[r, 6 * q: 6 * q + 6] = self._six(pos, lst, k)
+            hits = np.nonzero(np.isin(lst, pos))[0]
+            out[r, -2] = 1.0 / (hits[0] + 1) if len(hits) else np.nan
+            out[r, -1] = np.sum((np.arange(len(hits)) + 1) / (hits + 1)) / len(pos)
+        sums = np.concatenate([out[ev == 1].sum(0), [ev.sum()]])
+        return torch.from_numpy(out), torch.from_numpy(ev), torch.from_numpy(sums)
+
+    def auc_dense(self, user_ids, dense):
+        users, d = np.asarray(user_ids), dense.numpy()
+        out = np.full(len(users), np.nan)
+        for r, u in enumerate(users):
+            pos = self._row(self.tr, int(u))
+            if len(pos) == 0:
+                continue
+            cand = np.setdiff1d(np.arange(self.n_items), self._row(self.ex, int(u)))
+            out[r] = orc.auc(cand, d[r][cand], pos, np.setdiff1d(cand, pos))
+        return torch.from_numpy(out)
+
+    def rank_items(self, scores_row, items):
+        it = np.asarray(items)
+        return torch.from_numpy(orc.canonical_rank(it, scores_row.numpy()[it]).astype(np.int32))

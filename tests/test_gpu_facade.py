@@ -1,0 +1,197 @@
+"""GPU tests of the reference-shaped facade: Recommender.score / rank / recommend and
+ranking_eval with the reference's signatures, checked against outputs of the reference itself
+(tests/golden/*.npz) -- these read like the reference's own tests
+(tests/cornac/eval_methods/test_base_method.py:256-283, tests/cornac/models/test_recommender.py)."""
+import numpy as np
+import pytest
+
+from recommenders_amd import ScoreException, cache_rankings, ranking_eval
+from recommenders_amd import metrics as M
+from recommenders_amd.data import Dataset
+from recommenders_amd.models import BPR, MF, WMF
+from test_oracle import _csr
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _gpu():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+
+
+def _sets(d):
+    mk = lambda m: Dataset.from_csr(m)
+    return mk(_csr(d, "train")), mk(_csr(d, "test")), (mk(_csr(d, "val")) if "val_indptr" in d.files else None)
+
+
+def _model(d, name, train_set):
+    if name == "bpr":
+        m = BPR(k=d["bpr_U"].shape[1], init_params={"U": d["bpr_U"], "V": d["bpr_V"], "Bi": d["bpr_Bi"]})
+    elif name == "mf":
+        m = MF(k=d["mf_U"].shape[1], init_params={"U": d["mf_U"], "V": d["mf_V"], "Bu": d["mf_Bu"], "Bi": d["mf_Bi"],
+                                                 "mu": float(d["mf_mu"])})
+    else:
+        m = WMF(k=d["wmf_U"].shape[1], init_params={"U": d["wmf_U"], "V": d["wmf_V"]})
+    return m.fit(train_set)
+
+
+def _metrics(d):
+    out = []
+    for n in d["metric_names"]:
+        name, k = str(n).split("@")
+        out.append(M.AUC() if name == "auc" else {"ndcg": M.NDCG, "recall": M.Recall, "precision": M.Precision}[name](k=int(k)))
+    return out
+
+
+def _tie_free(d, model):
+    hs = d[f"{model}__ranked_head_scores"]
+    gaps = np.abs(np.diff(hs, axis=1))
+    return (gaps > 1e-5 * np.maximum(1e-3, np.abs(hs[:, :-1]))).all(axis=1)
+
+
+@pytest.mark.parametrize("name", ["bpr", "mf", "wmf"])
+def test_ranking_eval_matches_reference(toy, name):
+    d = toy
+    train_set, test_set, val_set = _sets(d)
+    model = _model(d, name, train_set)
+    mets = _metrics(d)
+    avg, per = ranking_eval(model, mets, train_set, test_set, val_set=val_set,
+                            rating_threshold=float(d["rating_threshold"]), exclude_unknowns=True)
+    users = d[f"{name}__users"]
+    assert sorted(per[0].keys()) == users.tolist()
+    ref, tf = d[f"{name}__per_user"], _tie_free(d, name)
+    for j, mt in enumerate(mets):
+        got = np.asarray([per[j][int(u)] for u in users])
+        if mt.name == "AUC":
+            assert np.abs(got - ref[:, j]).max() < 1e-4 and abs(got.mean() - ref[:, j].mean()) < 1e-6
+        else:
+            np.testing.assert_allclose(got[tf], ref[tf][:, j], atol=1e-6, rtol=0)
+            assert abs(got[tf].mean() - ref[tf][:, j].mean()) < 1e-6
+    np.testing.assert_allclose(avg, d[f"{name}__avg"], atol=2e-4, rtol=0)
+    # the three caches behave like the reference's dicts, lazily
+    u = int(users[np.flatnonzero(tf)[0]])
+    assert u in model.ranked_items and u in model.item_scores
+    r = np.flatnonzero(users == u)[0]
+    ranked = model.ranked_items[u]
+    np.testing.assert_array_equal(ranked[:19], d[f"{name}__ranked_head"][r][:19])
+    assert len(ranked) == d[f"{name}__n_cand"][r] == len(model.item_scores[u]) == len(model.item_scores_mapped_indices[u])
+    lut = dict(zip(model.item_scores_mapped_indices[u].tolist(), model.item_scores[u].tolist()))
+    np.testing.assert_allclose([lut[int(i)] for i in ranked[:19]], d[f"{name}__ranked_head_scores"][r][:19],
+                               rtol=1e-5, atol=1e-6)
+    rk, sc = cache_rankings(model, u, None)
+    assert rk is ranked
+
+
+@pytest.mark.parametrize("name", ["bpr", "mf", "wmf"])
+def test_score_and_rank_match_reference(toy, name):
+    d = toy
+    train_set, _, _ = _sets(d)
+    model = _model(d, name, train_set)
+    for u, ref in zip(d[f"{name}__score_users"], d[f"{name}__score_vecs"]):
+        s = model.score(int(u))
+        assert s.dtype == np.float32 and s.shape == ref.shape
+        np.testing.assert_allclose(s, ref, rtol=1e-5, atol=1e-6)
+        assert float(model.score(int(u), 3)) == pytest.approx(ref[3], rel=1e-5, abs=1e-6)
+    u = int(d[f"{name}__score_users"][0])
+    ranked, scores = model.rank(u)                                 # all known items
+    assert len(ranked) == model.num_items and len(scores) == model.num_items
+    s = model.score(u)
+    np.testing.assert_array_equal(ranked, np.lexsort((np.arange(len(s)), -s.astype(np.float64))))
+    cand = np.array([5, 3, 99, 42, 7])
+    ranked, scores = model.rank(u, item_indices=cand, k=2)
+    np.testing.assert_array_equal(scores, s[cand])                 # aligned with item_indices, not with the ranking
+    assert s[ranked[0]] >= s[ranked[1]] >= s[ranked[2:]].max()
+    with pytest.raises(ValueError):
+        model.rank(u, item_indices=cand, k=9)
+
+
+def test_unknown_users_follow_the_reference(toy):
+    d = toy
+    train_set, _, _ = _sets(d)
+    wmf = _model(d, "wmf", train_set)
+    with pytest.raises(ScoreException):
+        wmf.score(wmf.num_users + 5)
+    wmf.global_mean = 3.5
+    ranked, scores = wmf.rank(wmf.num_users + 5, item_indices=np.array([9, 2, 4]))
+    np.testing.assert_array_equal(ranked, [2, 4, 9])
+    np.testing.assert_array_equal(scores, [3.5, 3.5, 3.5])         # ones * default_score (recommender.py:626-627)
+    mf = _model(d, "mf", train_set)
+    s = mf.score(mf.num_users + 1)                                  # unknown user: mu + Bi only (recom_mf.py:276-280)
+    np.testing.assert_array_equal(s, (np.float32(d["mf_mu"]) + d["mf_Bi"]).astype(np.float32))
+
+
+def test_recommend_and_rank_batch(toy):
+    d = toy
+    train_set, _, _ = _sets(d)
+    model = _model(d, "bpr", train_set)
+    uid = model.user_ids[4]
+    rec = model.recommend(uid, k=10)
+    s = model.score(4)
+    np.testing.assert_array_equal(rec, np.lexsort((np.arange(len(s)), -s.astype(np.float64)))[:10])
+    rec2 = model.recommend(uid, k=10, remove_seen=True, train_set=train_set)
+    seen = set(train_set.csr_matrix.getrow(4).indices.tolist())
+    assert not (set(rec2) & seen) and rec != rec2 or not (set(rec) & seen)
+    with pytest.raises(ValueError):
+        model.recommend("nobody")
+    ids, scores = model.rank_batch(np.arange(50), 10, exclude_csr=train_set.csr_matrix)
+    for u in (0, 17, 49):
+        sv = model.score(u).astype(np.float64)
+        sv[train_set.csr_matrix.getrow(u).indices] = -np.inf
+        np.testing.assert_array_equal(ids[u], np.lexsort((np.arange(len(sv)), -sv))[:10])
+
+
+def test_c1_config_bpr_k50(c1):
+    """BASELINE.json configs[0]: BPR k=50, ML-100K shape, NDCG@10 / Recall@10 vs the reference run."""
+    d = c1
+    train_set, test_set, _ = _sets(d)
+    model = _model(d, "bpr", train_set)
+    avg, per = ranking_eval(model, [M.NDCG(k=10), M.Recall(k=10)], train_set, test_set,
+                            rating_threshold=float(d["rating_threshold"]))
+    users, ref, tf = d["bpr__users"], d["bpr__per_user"], _tie_free(d, "bpr")
+    assert len(per[0]) == len(users) and tf.mean() > 0.9
+    for j in range(2):
+        got = np.asarray([per[j][int(u)] for u in users])
+        np.testing.assert_allclose(got[tf], ref[tf][:, j], atol=1e-6, rtol=0)
+    np.testing.assert_allclose(avg, d["bpr__avg"], atol=1e-4, rtol=0)
+
+
+def test_unknown_items_are_rejected_loudly(unknowns):
+    d = unknowns
+    train_set, test_set, _ = _sets(d)
+    model = _model(d, "mf", train_set)
+    with pytest.raises(NotImplementedError):
+        ranking_eval(model, [M.NDCG(k=10)], train_set, test_set, rating_threshold=float(d["rating_threshold"]),
+                     exclude_unknowns=False)
+
+
+def test_metric_objects_compute_like_the_reference():
+    """Known answers of tests/cornac/metrics/test_ranking.py through the HIP metric kernels."""
+    import json
+    import os
+    from conftest import GOLDEN
+    known = json.load(open(os.path.join(GOLDEN, "ref_known_answers.json")))
+    A = np.asarray
+    for c in known["ndcg"]:
+        v = M.NDCG(k=c["k"]).compute(gt_pos=A(c["gt_pos"]), pd_rank=A(c["pd_rank"]))
+        assert (float("{:.2f}".format(v)) == c["expect_round2"]) if "expect_round2" in c else (v == c["expect"])
+    for key, cls in (("ncrr", M.NCRR), ("hit_ratio", M.HitRatio), ("precision", M.Precision), ("recall", M.Recall),
+                     ("f_measure", M.FMeasure)):
+        for c in known[key]:
+            exp = c["expect"] if "expect" in c else eval(c["expect_expr"])
+            assert cls(k=c["k"]).compute(A(c["gt_pos"]), A(c["pd_rank"])) == pytest.approx(exp, abs=1e-15)
+    for c in known["mrr"]:
+        if "raises" in c:
+            with pytest.raises(ValueError):
+                M.MRR().compute(A(c["gt_pos"]), A(c["pd_rank"]))
+        else:
+            assert M.MRR().compute(A(c["gt_pos"]), A(c["pd_rank"])) == c["expect"]
+    for c in known["auc"]:
+        gt_neg = None if c["gt_neg"] is None else np.flatnonzero(np.isin(c["item_indices"], c["gt_neg"]))
+        assert M.AUC().compute(A(c["item_indices"]), A(c["pd_scores"]), A(c["gt_pos"]), gt_neg) == c["expect"]
+    for c in known["map"]:
+        s = A(c["pd_scores"]) if "pd_scores" in c else np.linspace(*c["pd_scores_linspace_desc"][:2],
+                                                                   int(c["pd_scores_linspace_desc"][2]))[::-1]
+        exp = c["expect"] if "expect" in c else eval(c["expect_expr"])
+        assert M.MAP().compute(A(c["item_indices"]), s, A(c["gt_pos"])) == pytest.approx(exp, abs=1e-15)

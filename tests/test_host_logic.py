@@ -1,0 +1,206 @@
+"""CPU tests of the host side: C-ABI surface, CSR preparation, metric planning, result assembly
+and caches of recommenders_amd.eval, run against the oracle-backed fake engine and pinned by
+the reference-generated fixtures."""
+import ctypes
+import os
+import re
+import types
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from conftest import ROOT
+from fake_engine import OracleEngine
+from oracle import oracle as orc
+from recommenders_amd import _lib, dist as ifr_dist
+from recommenders_amd import eval as ifr_eval
+from recommenders_amd import metrics as M
+from recommenders_amd.data import Dataset
+from test_oracle import _csr
+
+
+# ------------------------------------------------------------------ C ABI surface
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "ifr.h")).read()
+    declared = sorted(set(re.findall(r"\b(ifr_[a-z_0-9]+)\s*\(", hdr)))
+    assert len(declared) >= 15
+    assert os.path.exists(_lib.LIB_PATH), "build libifr.so first (python -c 'import __graft_entry__ as g; g.build()')"
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/ifr.h but not exported"
+        assert name in _lib.SIGNATURES, f"{name} has no ctypes signature in recommenders_amd/_lib.py"
+    lib.ifr_version.restype = ctypes.c_char_p
+    assert b"gfx950" in lib.ifr_version()
+
+
+def test_no_oracle_import_in_product_package():
+    pkg = os.path.join(ROOT, "recommenders_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in txt.replace("ifr_oracle", "").lower() or f == "synth.py", (dirpath, f)
+
+
+# ------------------------------------------------------------------ fixtures -> datasets
+def _datasets(d):
+    train, test = _csr(d, "train"), _csr(d, "test")
+    val = _csr(d, "val") if "val_indptr" in d.files else None
+    mk = lambda m: None if m is None else Dataset.from_csr(m)
+    return mk(train), mk(test), mk(val)
+
+
+def _spec_objects(d):
+    out = []
+    for n in d["metric_names"]:
+        name, k = str(n).split("@")
+        k = int(k)
+        out.append({"ndcg": M.NDCG, "recall": M.Recall, "precision": M.Precision}[name](k=k) if name != "auc" else M.AUC())
+    return out
+
+
+def _engine(d, model, n_user_rows):
+    if model == "bpr":
+        U, V, ub, ib = d["bpr_U"], d["bpr_V"], None, d["bpr_Bi"]
+    elif model == "mf":
+        U, V, ub, ib = d["mf_U"], d["mf_V"], d["mf_Bu"], (np.float32(d["mf_mu"]) + d["mf_Bi"]).astype(np.float32)
+    else:
+        U, V, ub, ib = d["wmf_U"], d["wmf_V"], None, None
+    Ue = np.zeros((max(n_user_rows, len(U)) + 1, U.shape[1]), np.float32)
+    Ue[: len(U)] = U
+    if ub is not None:
+        ube = np.zeros(len(Ue), np.float32)
+        ube[: len(ub)] = ub
+        ub = ube
+    return OracleEngine(Ue, V, ub, ib)
+
+
+def test_build_eval_csrs_matches_reference_rule(toy):
+    d = toy
+    train, test, val = _csr(d, "train"), _csr(d, "test"), _csr(d, "val")
+    thr, ni = float(d["rating_threshold"]), int(d["num_items"])
+    truth, excl, has_pos = ifr_eval.build_eval_csrs(train, test, val, thr, ni, test.shape[0])
+    for u in range(test.shape[0]):
+        sets = orc.eval_sets(train, test, val, u, thr, ni, test.shape[1], True)
+        if sets is None:
+            assert not has_pos[u]
+            continue
+        item_indices, gt_pos, gt_neg = sets
+        assert has_pos[u]
+        np.testing.assert_array_equal(truth[u].indices, gt_pos)
+        cand = np.setdiff1d(np.arange(ni), excl[u].indices)
+        np.testing.assert_array_equal(cand, item_indices)
+
+
+@pytest.mark.parametrize("model", ["bpr", "mf", "wmf"])
+def test_ranking_eval_host_logic_against_reference(toy, model):
+    d = toy
+    train_set, test_set, val_set = _datasets(d)
+    fake_model = types.SimpleNamespace(is_fitted=True)
+    eng = _engine(d, model, test_set.num_users)
+    mets = _spec_objects(d)
+    avg, per = ifr_eval.ranking_eval(fake_model, mets, train_set, test_set, val_set,
+                                     rating_threshold=float(d["rating_threshold"]), exclude_unknowns=True, _engine=eng)
+    users = d[f"{model}__users"]
+    assert sorted(per[0].keys()) == users.tolist()
+    ref = d[f"{model}__per_user"]
+    ref_hs = d[f"{model}__ranked_head_scores"]
+    gaps = np.abs(np.diff(ref_hs, axis=1))
+    tie_free = (gaps > 1e-5 * np.maximum(1e-3, np.abs(ref_hs[:, :-1]))).all(axis=1)
+    for j in range(len(mets)):
+        got = np.asarray([per[j][int(u)] for u in users])
+        if mets[j].name == "AUC":
+            assert np.abs(got - ref[:, j]).max() < 1e-4
+        else:
+            np.testing.assert_allclose(got[tie_free], ref[tie_free][:, j], atol=1e-9, rtol=0)
+        assert avg[j] == pytest.approx(got.mean(), abs=1e-12)
+    np.testing.assert_allclose(avg, d[f"{model}__avg"], atol=2e-4, rtol=0)
+
+
+def test_ranking_eval_full_list_metrics_and_errors(toy):
+    d = toy
+    train_set, test_set, val_set = _datasets(d)
+    eng = _engine(d, "bpr", test_set.num_users)
+    fake = types.SimpleNamespace(is_fitted=True)
+    mets = [M.NDCG(k=-1), M.Recall(k=50), M.MRR(), M.MAP(), M.HitRatio(k=10), M.FMeasure(k=10), M.NCRR(k=10)]
+    avg, per = ifr_eval.ranking_eval(fake, mets, train_set, test_set, val_set,
+                                     rating_threshold=float(d["rating_threshold"]), _engine=eng)
+    # cross-check three users against the NumPy restatement of the reference classes
+    train, test, val = _csr(d, "train"), _csr(d, "test"), _csr(d, "val")
+    for u in list(per[0].keys())[:3]:
+        item_indices, gt_pos, _ = orc.eval_sets(train, test, val, u, float(d["rating_threshold"]),
+                                                int(d["num_items"]), test.shape[1], True)
+        s = orc.score_bpr(d["bpr_U"], d["bpr_V"], d["bpr_Bi"], u)
+        rank = orc.canonical_rank(item_indices, s[item_indices])
+        exp = [orc.ndcg(gt_pos, rank, -1), orc.recall(gt_pos, rank, 50), orc.mrr(gt_pos, rank),
+               orc.average_precision(item_indices, s[item_indices].astype(np.float64), gt_pos),
+               orc.hit_ratio(gt_pos, rank, 10), orc.f_measure(gt_pos, rank, 10), orc.ncrr(gt_pos, rank, 10)]
+        for j in range(len(mets)):
+            assert per[j][u] == pytest.approx(exp[j], abs=1e-9)
+    assert ifr_eval.ranking_eval(fake, [], train_set, test_set) == ([], [])
+    with pytest.raises(RuntimeError):
+        ifr_eval.ranking_eval(types.SimpleNamespace(is_fitted=False), mets, train_set, test_set, _engine=eng)
+    with pytest.raises(TypeError):
+        ifr_eval.ranking_eval(fake, mets, train_set, test_set)          # no HIP path, no fallback
+    empty = Dataset.from_csr(sp.csr_matrix(test_set.csr_matrix.shape))
+    with pytest.raises(ZeroDivisionError):
+        ifr_eval.ranking_eval(fake, [M.NDCG(k=10)], train_set, empty, _engine=eng)
+
+
+def test_plan_metrics_and_names():
+    specs, ks, need_auc, need_list = ifr_eval.plan_metrics([M.NDCG(k=10), M.Recall(k=10), M.Precision(k=5)])
+    assert specs == [("ndcg", 10), ("recall", 10), ("precision", 5)] and ks == [5, 10] and not need_auc and not need_list
+    assert ifr_eval.plan_metrics([M.AUC()])[2] is True
+    assert ifr_eval.plan_metrics([M.NDCG()])[3] is True and ifr_eval.plan_metrics([M.Recall(k=100)])[3] is True
+    assert M.NDCG(k=10).name == "NDCG@10" and M.NDCG().name == "NDCG@-1" and M.FMeasure(k=2).name == "F1@2"
+    assert M.AUC().name == "AUC" and M.MRR().name == "MRR" and M.MAP().name == "MAP" and M.NDCG().type == "ranking"
+    with pytest.raises(TypeError):
+        ifr_eval.plan_metrics([types.SimpleNamespace(k=3, name="Gini")])
+
+
+def test_shard_range_partitions():
+    for n in (0, 1, 7, 138493):
+        for world in (1, 2, 3, 8):
+            parts = [ifr_dist.shard_range(n, r, world) for r in range(world)]
+            assert parts[0][0] == 0 and parts[-1][1] == n
+            assert all(parts[i][1] == parts[i + 1][0] for i in range(world - 1))
+            sizes = [hi - lo for lo, hi in parts]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_lazy_cache_and_cache_rankings():
+    calls = []
+
+    class Model:
+        is_fitted = True
+
+        def __init__(self):
+            self.ranked_items, self.item_scores, self.item_scores_mapped_indices = {}, {}, {}
+
+        def rank(self, user_idx, item_indices=None, k=-1):
+            calls.append(user_idx)
+            r = np.asarray(item_indices)[::-1].copy()
+            self.ranked_items[user_idx] = r
+            self.item_scores[user_idx] = np.zeros(len(r))
+            self.item_scores_mapped_indices[user_idx] = np.asarray(item_indices)
+            return r, self.item_scores[user_idx]
+
+    m = Model()
+    excl = sp.csr_matrix(np.array([[1, 0, 0, 0], [0, 0, 1, 1]], dtype=np.int8))
+    owner = ifr_eval._CacheOwner(m, excl, 4, np.array([0, 1]))
+    for f in ("ranked_items", "item_scores", "item_scores_mapped_indices"):
+        setattr(m, f, ifr_eval.LazyRankCache(owner, f, owner.users, {}))
+    assert 1 in m.ranked_items and 5 not in m.ranked_items and len(m.ranked_items) == 2 and not calls
+    np.testing.assert_array_equal(m.ranked_items[1], [1, 0])          # candidates {0, 1}, reversed by the stub
+    assert calls == [1]
+    np.testing.assert_array_equal(m.item_scores_mapped_indices[1], [0, 1])
+    r, s = ifr_eval.cache_rankings(m, 1, np.arange(4))                  # cache hit: item_indices ignored (:166-167)
+    np.testing.assert_array_equal(r, [1, 0])
+    assert calls == [1]
+    ifr_eval.cache_rankings(m, 0, np.array([1, 2, 3]))
+    assert calls == [1, 0]
+    with pytest.raises(RuntimeError):
+        ifr_eval.cache_rankings(types.SimpleNamespace(is_fitted=False), 0, None)
+    import pickle
+    assert isinstance(pickle.loads(pickle.dumps(m.ranked_items)), dict)
