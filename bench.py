@@ -59,6 +59,16 @@ def cpu_strong(w, n_sample):
     return dict(value=done / dt, unit="users/s", kind="numpy sgemm+argpartition", sample=f"{done} users, {dt:.1f} s")
 
 
+def measured_traffic(config, n_users, n_items):
+    """HBM bytes per launch of the fused kernel from the committed rocprofv3 PMC passes of this same
+    command (profiles/*_pmc.json, made by tools/prof_c2.sh); None when the workload differs."""
+    path = os.path.join(ROOT, "profiles", "r01_c2_pmc.json")
+    if config != "c2_wmf_ml20m" or (n_users, n_items) != (138493, 26744) or not os.path.exists(path):
+        return None
+    with open(path) as f:
+        return json.load(f)["hbm_traffic_per_launch_bytes"]["total_corrected"]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -152,7 +162,8 @@ def main():
                        "users_per_gpu": n, "items": w["n_items"], "k": w["k"], "topk": TOPK,
                        "parallelism": f"users sharded x{world}, item factors replicated"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                         "frac": achieved / PEAK_F32_MFMA_TFLOPS,
+                         "traffic": measured_traffic(args.config, n, w["n_items"]),
                          "kernel": "score_topk_kernel", "avg_launch_ms": avg_ms, "launches": launches,
                          "flops_per_launch": flops_per_launch},
             "eval": {"ndcg@10": sums[0] / sums[-1], "recall@10": sums[1] / sums[-1],
