@@ -59,6 +59,36 @@ int ifr_set_option(ifr_handle h, const char *name, int64_t value);
 int ifr_set_factors(ifr_handle h, const float *U, int64_t n_users, const float *V, int64_t n_items,
                     int k, const float *ubase, const float *ibase);
 
+/* Item-item models: score(u, :) = (sum_{j in hist(u)} x_uj * M[j, :]) * col_scale, the other model
+ * family of the path.  Replaces the parameter reads of EASE.score (cornac/models/ease/recom_ease.py:
+ * 123-124: M = B, hist(u) = row u of train_set.matrix with its ratings, col_scale NULL) and of
+ * RP3_Beta.score (cornac/models/rp3_beta/graph_recommender.py:97-117 and recom_rp3beta.py:122: in
+ * item-item form M = W = P_iu.P_ui, x_uj = 1/deg(u), col_scale = 1/deg(item)^beta).
+ * Setting an item matrix replaces any factors set before (and the other way round); ifr_rank_topk,
+ * ifr_score_dense and everything downstream then serve the item-item model.
+ *   dense:  M [n_items][ld] row-major fp32, ld >= n_items.  Per (user, item) one fp32 fma chain
+ *           over the history row in its CSR order, then one fp32 multiply by col_scale.
+ *   csr:    rows of M with strictly ascending columns.  Products are exact (fp64), scaled by
+ *           2^shift (ifr_item_fixed_point_shift), rounded to nearest even and summed as 64-bit
+ *           integers, so the result does not depend on summation order; the sum is rounded once
+ *           to fp64, once to fp32 and multiplied by col_scale in fp32.
+ * col_scale: [n_items] or NULL.  "any" pointers. */
+int ifr_set_item_matrix_dense(ifr_handle h, const float *M, int64_t n_items, int64_t ld, const float *col_scale);
+int ifr_set_item_matrix_csr(ifr_handle h, const int64_t *indptr, const int32_t *indices, const float *values,
+                            int64_t n_items, int64_t nnz, const float *col_scale);
+
+/* Per-user histories of an item-item model: row u = the items and weights x_uj that enter user u's
+ * score (EASE: train_set.matrix, recom_ease.py:75; RP3-beta: the user's train items, each weighted
+ * 1/deg(u), graph_recommender.py:53-55).  Users >= n_rows have an empty history (score 0).
+ * Call after ifr_set_item_matrix_*: item ids are validated against its n_items.  "any" pointers. */
+int ifr_set_history_csr(ifr_handle h, const int64_t *indptr, const int32_t *indices, const float *values,
+                        int64_t n_rows, int64_t nnz);
+
+/* The power-of-two scale of the fixed-point accumulation of a CSR item matrix, derived from
+ * max|M| and the largest history L1 norm so that no sum can overflow; lets a CPU checker
+ * reproduce the scores bit-for-bit (no reference counterpart).  Needs matrix and histories set. */
+int ifr_item_fixed_point_shift(ifr_handle h, int *shift);
+
 /* Per-user exclusion lists = items that must not be ranked: (train U validation positives)
  * minus test positives, already filtered by rating_threshold and clipped to [0, n_items)
  * (cornac/eval_methods/base_method.py:246-251, 265-283; SURVEY.md Appendix B rules 2-3).

@@ -259,6 +259,113 @@ int orc_ranking_eval_factor(
     return 0;
 }
 
+/* ------------------------------------------------------------------ */
+/* a7/a8: item-item models, one user's score vector                    */
+/*   EASE  recom_ease.py:123-124   s = X[u,:] . B                       */
+/*   RP3   graph_recommender.py:97-117 in item-item form                */
+/*         s = (P_ui[u,:] . W) * 1/deg^beta,  W = P_iu . P_ui           */
+/* The reference computes both in fp64 (and rounds P, P2, P3 to fp32    */
+/* for RP3); the north star allows 1e-5 relative on scores.  These two  */
+/* restatements follow the arithmetic the HIP path documents            */
+/* (include/ifr.h) so that it can be compared bit-for-bit:              */
+/*  dense: per item one fp32 fma chain over the history in CSR order,   */
+/*         then one fp32 multiply by col_scale;                         */
+/*  csr:   exact fp64 products scaled by 2^shift, rounded to nearest    */
+/*         even, summed as int64 (order-free), rounded to fp64, to      */
+/*         fp32, then multiplied by col_scale in fp32.                  */
+/* tests/test_oracle.py pins both against the reference's own EASE and  */
+/* RP3 outputs (tests/golden/toy_all_models.npz) within 1e-5 relative.  */
+/* ------------------------------------------------------------------ */
+void orc_score_item_dense(const float *M, int64_t ld, int n_items,
+                          const int32_t *h_idx, const float *h_val, int n_hist,
+                          const float *col_scale, float *out)
+{
+    for (int c = 0; c < n_items; ++c) {
+        float acc = 0.0f;
+        for (int e = 0; e < n_hist; ++e)
+            acc = fmaf(h_val[e], M[(size_t)h_idx[e] * (size_t)ld + (size_t)c], acc);
+        out[c] = col_scale ? acc * col_scale[c] : acc;
+    }
+}
+
+/* returns 0, or -1 if a fixed-point sum left the 62-bit range the shift must guarantee */
+int orc_score_item_csr(const int64_t *m_ptr, const int32_t *m_idx, const float *m_val, int n_items,
+                       const int32_t *h_idx, const float *h_val, int n_hist,
+                       int shift, const float *col_scale, float *out)
+{
+    int64_t *acc = (int64_t *)calloc((size_t)(n_items > 0 ? n_items : 1), sizeof(int64_t));
+    int rc = 0;
+    for (int e = 0; e < n_hist; ++e) {
+        const double x = (double)h_val[e];
+        const int j = h_idx[e];
+        for (int64_t q = m_ptr[j]; q < m_ptr[j + 1]; ++q) {
+            const double pr = x * (double)m_val[q];              /* exact */
+            acc[m_idx[q]] += llrint(ldexp(pr, shift));           /* nearest even */
+        }
+    }
+    for (int c = 0; c < n_items; ++c) {
+        if (acc[c] > ((int64_t)1 << 62) || acc[c] < -((int64_t)1 << 62)) rc = -1;
+        const float s = (float)ldexp((double)acc[c], -shift);
+        out[c] = col_scale ? s * col_scale[c] : s;
+    }
+    free(acc);
+    return rc;
+}
+
+/* a9 for item-item models: the per-user loop of ranking_eval (base_method.py:253-303) with the   */
+/* scores above; same outputs as orc_ranking_eval_factor.  Exactly one of M / m_ptr is given.     */
+int orc_ranking_eval_item(
+    const float *M, int64_t ld,
+    const int64_t *m_ptr, const int32_t *m_idx, const float *m_val, int shift,
+    int n_items, const float *col_scale,
+    const int64_t *h_ptr, const int32_t *h_idx, const float *h_val, int64_t h_rows,
+    const int32_t *users, int n,
+    const int64_t *excl_ptr, const int32_t *excl_idx, int64_t excl_rows,
+    const int64_t *truth_ptr, const int32_t *truth_idx, int64_t truth_rows,
+    const int32_t *ks, int n_k, int want_auc, int kmax,
+    int32_t *out_ids, float *out_scores, double *out_metrics, int32_t *evaluated,
+    int n_threads)
+{
+    int stride = n_k * 3 + 1;
+    int bad = 0;
+#ifdef _OPENMP
+    if (n_threads > 0) omp_set_num_threads(n_threads);
+#pragma omp parallel
+#endif
+    {
+        float *scores = (float *)malloc(sizeof(float) * (size_t)n_items);
+#ifdef _OPENMP
+#pragma omp for schedule(dynamic, 4)
+#endif
+        for (int i = 0; i < n; ++i) {
+            int u = users[i];
+            const int32_t *ex = NULL, *pos = NULL, *hi = NULL;
+            const float *hv = NULL;
+            int n_ex = 0, n_pos = 0, n_h = 0;
+            if (excl_ptr && u < excl_rows) { ex = excl_idx + excl_ptr[u]; n_ex = (int)(excl_ptr[u + 1] - excl_ptr[u]); }
+            if (truth_ptr && u < truth_rows) { pos = truth_idx + truth_ptr[u]; n_pos = (int)(truth_ptr[u + 1] - truth_ptr[u]); }
+            if (u < h_rows) { hi = h_idx + h_ptr[u]; hv = h_val + h_ptr[u]; n_h = (int)(h_ptr[u + 1] - h_ptr[u]); }
+            int32_t *ids = out_ids + (size_t)i * kmax;
+            float *sc = out_scores + (size_t)i * kmax;
+            double *m = out_metrics + (size_t)i * stride;
+            if (M) orc_score_item_dense(M, ld, n_items, hi, hv, n_h, col_scale, scores);
+            else if (orc_score_item_csr(m_ptr, m_idx, m_val, n_items, hi, hv, n_h, shift, col_scale, scores)) bad = 1;
+            int n_cand = orc_rank_topk(scores, n_items, ex, n_ex, kmax, ids, sc);
+            evaluated[i] = n_pos > 0;
+            if (n_pos == 0) {
+                for (int j = 0; j < stride; ++j) m[j] = NAN;
+                continue;
+            }
+            int n_ranked = kmax < n_cand ? kmax : n_cand;
+            for (int j = 0; j < n_k; ++j)
+                orc_metrics_at_k(ids, n_ranked, n_cand, pos, n_pos, ks[j], m + 3 * j);
+            m[n_k * 3] = want_auc ? orc_auc(scores, n_items, ex, n_ex, pos, n_pos) : NAN;
+        }
+        free(scores);
+    }
+    return bad ? -1 : 0;
+}
+
 int orc_max_threads(void)
 {
 #ifdef _OPENMP

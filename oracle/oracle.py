@@ -351,3 +351,105 @@ def c_ranking_eval_factor(U, V, ibase, ubase, users, excl_ptr, excl_idx, truth_p
         _p(ids, ctypes.c_int32), _p(sc, ctypes.c_float), _p(met, ctypes.c_double), _p(ev, ctypes.c_int32),
         int(n_threads))
     return ids, sc, met, ev
+
+
+def _i64(a):
+    return np.ascontiguousarray(a, np.int64)
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, np.int32)
+
+
+def _f32(a):
+    return None if a is None else np.ascontiguousarray(a, np.float32)
+
+
+def c_score_item_dense(M, h_idx, h_val, col_scale=None):
+    """orc_score_item_dense: fp32 fma chain over the history in order, then * col_scale."""
+    M = np.ascontiguousarray(M, np.float32)
+    h_idx, h_val, cs = _i32(h_idx), _f32(h_val), _f32(col_scale)
+    out = np.empty(M.shape[0], np.float32)
+    c_lib().orc_score_item_dense(_p(M, ctypes.c_float), ctypes.c_int64(M.shape[1]), M.shape[0],
+                                 _p(h_idx, ctypes.c_int32), _p(h_val, ctypes.c_float), len(h_idx),
+                                 _p(cs, ctypes.c_float), _p(out, ctypes.c_float))
+    return out
+
+
+def c_score_item_csr(m_ptr, m_idx, m_val, n_items, h_idx, h_val, shift, col_scale=None):
+    """orc_score_item_csr: 2^shift fixed-point accumulation (order-free), then * col_scale."""
+    m_ptr, m_idx, m_val = _i64(m_ptr), _i32(m_idx), _f32(m_val)
+    h_idx, h_val, cs = _i32(h_idx), _f32(h_val), _f32(col_scale)
+    out = np.empty(n_items, np.float32)
+    rc = c_lib().orc_score_item_csr(_p(m_ptr, ctypes.c_int64), _p(m_idx, ctypes.c_int32), _p(m_val, ctypes.c_float),
+                                    int(n_items), _p(h_idx, ctypes.c_int32), _p(h_val, ctypes.c_float), len(h_idx),
+                                    int(shift), _p(cs, ctypes.c_float), _p(out, ctypes.c_float))
+    if rc != 0:
+        raise OverflowError("fixed-point sum left the 62-bit range: shift too large for these inputs")
+    return out
+
+
+def c_ranking_eval_item(M, m_csr, shift, n_items, col_scale, h_ptr, h_idx, h_val, users, excl_ptr, excl_idx,
+                        truth_ptr, truth_idx, ks, want_auc, kmax, n_threads=1):
+    """orc_ranking_eval_item.  M: dense [I, ld] fp32 or None; m_csr: (ptr, idx, val) or None."""
+    users = _i32(users)
+    n = len(users)
+    ks = _i32(ks)
+    h_ptr, h_idx, h_val = _i64(h_ptr), _i32(h_idx), _f32(h_val)
+    excl_ptr, excl_idx = _i64(excl_ptr), _i32(excl_idx)
+    truth_ptr, truth_idx = _i64(truth_ptr), _i32(truth_idx)
+    cs = _f32(col_scale)
+    if M is not None:
+        M = np.ascontiguousarray(M, np.float32)
+        mp = mi = mv = None
+        ld = M.shape[1]
+    else:
+        mp, mi, mv = _i64(m_csr[0]), _i32(m_csr[1]), _f32(m_csr[2])
+        ld = 0
+    ids = np.empty((n, kmax), np.int32)
+    sc = np.empty((n, kmax), np.float32)
+    met = np.empty((n, 3 * len(ks) + 1), np.float64)
+    ev = np.empty(n, np.int32)
+    rc = c_lib().orc_ranking_eval_item(
+        _p(M, ctypes.c_float), ctypes.c_int64(ld),
+        _p(mp, ctypes.c_int64), _p(mi, ctypes.c_int32), _p(mv, ctypes.c_float), int(shift),
+        int(n_items), _p(cs, ctypes.c_float),
+        _p(h_ptr, ctypes.c_int64), _p(h_idx, ctypes.c_int32), _p(h_val, ctypes.c_float), ctypes.c_int64(len(h_ptr) - 1),
+        _p(users, ctypes.c_int32), n,
+        _p(excl_ptr, ctypes.c_int64), _p(excl_idx, ctypes.c_int32), ctypes.c_int64(len(excl_ptr) - 1),
+        _p(truth_ptr, ctypes.c_int64), _p(truth_idx, ctypes.c_int32), ctypes.c_int64(len(truth_ptr) - 1),
+        _p(ks, ctypes.c_int32), len(ks), int(want_auc), int(kmax),
+        _p(ids, ctypes.c_int32), _p(sc, ctypes.c_float), _p(met, ctypes.c_double), _p(ev, ctypes.c_int32),
+        int(n_threads))
+    if rc != 0:
+        raise OverflowError("fixed-point sum left the 62-bit range")
+    return ids, sc, met, ev
+
+
+def item_fixed_point_shift(m_val, h_ptr, h_val):
+    """The shift rule documented in include/ifr.h (ifr_item_fixed_point_shift): the largest power of
+    two such that max|M| * max_u sum_j |x_uj| * 1.001 * 2^shift <= 2^61."""
+    import math
+    maxabs = float(np.max(np.abs(np.asarray(m_val, np.float32)))) if len(m_val) else 0.0
+    h_ptr = np.asarray(h_ptr, np.int64)
+    l1 = np.add.reduceat(np.abs(np.asarray(h_val, np.float64)), h_ptr[:-1][np.diff(h_ptr) > 0]) if len(h_val) else np.zeros(0)
+    l1max = float(np.nextafter(np.float32(l1.max()), np.float32(np.inf))) if len(l1) else 0.0
+    bound = maxabs * l1max * 1.001
+    if not bound > 0.0:
+        return 0
+    _, e = math.frexp(bound)
+    return max(-960, min(960, 61 - e))
+
+
+def rp3_model_arrays(train_csr, beta):
+    """Host arrays of the item-item form of RP3-beta from a (binarised) train matrix:
+    (P_ui csr fp32 = histories, W csr fp32, col_scale fp32 = 1/deg^beta), following
+    graph_recommender.py:24-55, 83-84, 104-115 (zero-degree items: 1/0**beta = inf)."""
+    P_ui, W, deg = rp3_item_item(train_csr)
+    with np.errstate(divide="ignore"):
+        pen = (1.0 / (deg.astype(np.float64) ** beta)).astype(np.float32)
+    P32 = P_ui.astype(np.float32)
+    W32 = W.astype(np.float32)
+    W32.sort_indices()
+    P32.sort_indices()
+    return P32, W32, pen

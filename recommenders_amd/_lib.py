@@ -24,6 +24,10 @@ SIGNATURES = {
     "ifr_last_error": (ctypes.c_char_p, [vp]),
     "ifr_set_option": (ctypes.c_int, [vp, ctypes.c_char_p, ctypes.c_int64]),
     "ifr_set_factors": (ctypes.c_int, [vp, vp, ctypes.c_int64, vp, ctypes.c_int64, ctypes.c_int, vp, vp]),
+    "ifr_set_item_matrix_dense": (ctypes.c_int, [vp, vp, ctypes.c_int64, ctypes.c_int64, vp]),
+    "ifr_set_item_matrix_csr": (ctypes.c_int, [vp, vp, vp, vp, ctypes.c_int64, ctypes.c_int64, vp]),
+    "ifr_set_history_csr": (ctypes.c_int, [vp, vp, vp, vp, ctypes.c_int64, ctypes.c_int64]),
+    "ifr_item_fixed_point_shift": (ctypes.c_int, [vp, ctypes.POINTER(ctypes.c_int)]),
     "ifr_set_exclusion_csr": (ctypes.c_int, [vp, vp, vp, ctypes.c_int64, ctypes.c_int64]),
     "ifr_set_truth_csr": (ctypes.c_int, [vp, vp, vp, ctypes.c_int64, ctypes.c_int64]),
     "ifr_rank_topk": (ctypes.c_int, [vp, vp, ctypes.c_int64, ctypes.c_int, vp, vp, vp]),

@@ -13,6 +13,7 @@
 
 #include "../../include/ifr.h"
 #include "ifr_kernels.h"
+#include "ifr_itemitem.h"
 
 namespace ifr {
 // implemented in ifr_aux.hip
@@ -27,6 +28,8 @@ int launch_rank_full(const float *scores, int64_t ld, const int32_t *user_ids, i
                      int32_t *out_ids, int32_t *n_cand, void **ws, size_t *ws_bytes, hipStream_t stream);
 }  // namespace ifr
 
+enum { MODE_NONE = 0, MODE_FACTOR = 1, MODE_ITEM_DENSE = 2, MODE_ITEM_CSR = 3 };
+
 struct ifr_handle_s {
     int device = 0;
     std::string err;
@@ -35,6 +38,17 @@ struct ifr_handle_s {
     int64_t n_users = 0, n_items = 0;
     int k = 0, KD = 0, n_tiles = 0;
     bool has_base = false;
+    int mode = MODE_NONE;
+    // item-item model: dense M or chunk-blocked CSR, column scale, user histories
+    float *iiM = nullptr; int64_t ii_ld = 0;
+    int64_t *ii_cptr = nullptr; int32_t *ii_idx = nullptr; float *ii_val = nullptr; int64_t ii_nnz = 0;
+    float *ii_pen = nullptr;
+    int ii_chunks = 0;
+    float ii_maxabs = 0.f;
+    int64_t *hs_ptr = nullptr; int32_t *hs_idx = nullptr; float *hs_val = nullptr;
+    int64_t hs_rows = 0, hs_nnz = 0;
+    float hs_l1max = 0.f;
+    double prof_bytes = 0.0;
     // exclusions: raw CSR (AUC / full rank) + tile-encoded lists (fused kernel)
     int64_t *ex_ptr = nullptr;
     int32_t *ex_idx = nullptr, *ex_cnt = nullptr, *ex_tile = nullptr;
@@ -126,6 +140,57 @@ void launch_dense(bool has_base, const ifr::DenseParams &p, int grid, hipStream_
     else hipLaunchKernelGGL((ifr::score_dense_kernel<KD, false>), dim3(grid), dim3(ifr::BLOCK), 0, s, p);
 }
 
+void clear_item_model(ifr_handle h)
+{
+    dfree(h->iiM); dfree(h->ii_cptr); dfree(h->ii_idx); dfree(h->ii_val); dfree(h->ii_pen);
+    dfree(h->hs_ptr); dfree(h->hs_idx); dfree(h->hs_val);
+    h->ii_ld = 0; h->ii_nnz = 0; h->ii_chunks = 0; h->ii_maxabs = 0.f;
+    h->hs_rows = 0; h->hs_nnz = 0; h->hs_l1max = 0.f;
+    if (h->mode == MODE_ITEM_DENSE || h->mode == MODE_ITEM_CSR) { h->mode = MODE_NONE; h->n_items = 0; }
+}
+
+void clear_factor_model(ifr_handle h)
+{
+    dfree(h->U); dfree(h->V); dfree(h->ibase); dfree(h->ubase);
+    h->n_users = 0; h->k = 0; h->KD = 0; h->n_tiles = 0; h->has_base = false;
+    if (h->mode == MODE_FACTOR) { h->mode = MODE_NONE; h->n_items = 0; }
+}
+
+// CSR data was laid out for another catalogue: drop it rather than index out of range later
+void drop_csrs_if_catalogue_changes(ifr_handle h, int64_t n_items)
+{
+    if (h->n_items == n_items) return;
+    dfree(h->ex_ptr); dfree(h->ex_idx); dfree(h->ex_cnt); dfree(h->ex_tile); dfree(h->ex_mask);
+    h->ex_rows = 0; h->ex_nnz = 0;
+}
+
+// column scale padded to whole chunks (the kernels read it 16 B at a time)
+int set_col_scale(ifr_handle h, const float *col_scale, int64_t n_items, int64_t padded)
+{
+    dfree(h->ii_pen);
+    if (!col_scale) return IFR_OK;
+    IFR_HIP(h, hipMalloc((void **)&h->ii_pen, sizeof(float) * padded));
+    IFR_HIP(h, hipMemset(h->ii_pen, 0, sizeof(float) * padded));
+    IFR_HIP(h, hipMemcpy(h->ii_pen, col_scale, sizeof(float) * n_items, hipMemcpyDefault));
+    return IFR_OK;
+}
+
+// 2^shift: the largest power of two for which |sum_j x_uj M[j,c]| * 2^shift <= 2^61 for every user
+int fixed_point_shift(ifr_handle h)
+{
+    const double bound = (double)h->ii_maxabs * (double)h->hs_l1max * 1.001;
+    if (!(bound > 0.0)) return 0;
+    int e = 0;
+    (void)std::frexp(bound, &e);                 // bound <= 2^e
+    return std::max(-960, std::min(960, 61 - e));
+}
+
+int read_flag_and_max(ifr_handle h, const void *dev, uint32_t *out)
+{
+    IFR_HIP(h, hipMemcpy(out, dev, sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return IFR_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -161,6 +226,8 @@ int ifr_destroy(ifr_handle h)
     dfree(h->U); dfree(h->V); dfree(h->ibase); dfree(h->ubase);
     dfree(h->ex_ptr); dfree(h->ex_idx); dfree(h->ex_cnt); dfree(h->ex_tile); dfree(h->ex_mask);
     dfree(h->tr_ptr); dfree(h->tr_idx); dfree(h->discount);
+    dfree(h->iiM); dfree(h->ii_cptr); dfree(h->ii_idx); dfree(h->ii_val); dfree(h->ii_pen);
+    dfree(h->hs_ptr); dfree(h->hs_idx); dfree(h->hs_val);
     dfree(h->ws_part); dfree(h->ws_met); dfree(h->ws_sort);
     for (auto &e : h->ev_used) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     for (auto &e : h->ev_free) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
@@ -190,6 +257,7 @@ int ifr_set_factors(ifr_handle h, const float *U, int64_t n_users, const float *
     if (n_items > (int64_t)1 << 30) return fail(h, IFR_ERR_ARG, "ifr_set_factors: n_items too large");
     IFR_HIP(h, hipSetDevice(h->device));
     dfree(h->U); dfree(h->V); dfree(h->ibase); dfree(h->ubase);
+    clear_item_model(h);
     const int KD = pad_k(k);
     const int n_tiles = (int)((n_items + ifr::TILE_I - 1) / ifr::TILE_I);
     const int64_t v_rows = (int64_t)(n_tiles + 1) * ifr::TILE_I;
@@ -206,7 +274,9 @@ int ifr_set_factors(ifr_handle h, const float *U, int64_t n_users, const float *
     if (ibase) IFR_HIP(h, hipMemcpy(h->ibase, ibase, sizeof(float) * n_items, hipMemcpyDefault));
     if (ubase) IFR_HIP(h, hipMemcpy(h->ubase, ubase, sizeof(float) * n_users, hipMemcpyDefault));
     h->has_base = (ibase != nullptr) || (ubase != nullptr);
+    drop_csrs_if_catalogue_changes(h, n_items);
     h->n_users = n_users; h->n_items = n_items; h->k = k; h->KD = KD; h->n_tiles = n_tiles;
+    h->mode = MODE_FACTOR;
     // CSR data set for another catalogue size would index out of range
     return IFR_OK;
 }
@@ -268,16 +338,210 @@ int ifr_set_truth_csr(ifr_handle h, const int64_t *indptr, const int32_t *indice
     return IFR_OK;
 }
 
+
+int ifr_set_item_matrix_dense(ifr_handle h, const float *M, int64_t n_items, int64_t ld, const float *col_scale)
+{
+    if (!h) return IFR_ERR_ARG;
+    if (!M || n_items <= 0 || ld < n_items) return fail(h, IFR_ERR_ARG, "ifr_set_item_matrix_dense: null/empty input or ld < n_items");
+    if (n_items > (int64_t)1 << 30) return fail(h, IFR_ERR_ARG, "ifr_set_item_matrix_dense: n_items too large");
+    IFR_HIP(h, hipSetDevice(h->device));
+    const int64_t old_items = h->n_items;
+    clear_factor_model(h);
+    clear_item_model(h);
+    h->n_items = old_items;
+    drop_csrs_if_catalogue_changes(h, n_items);
+    h->n_items = 0;
+    const int chunk = ifr::item_item_chunk(false), pass = ifr::item_item_pass();
+    const int64_t ldm = (n_items + pass - 1) / pass * pass;
+    IFR_HIP(h, hipMalloc((void **)&h->iiM, sizeof(float) * n_items * ldm));
+    if (ldm != n_items) IFR_HIP(h, hipMemset(h->iiM, 0, sizeof(float) * n_items * ldm));
+    IFR_HIP(h, hipMemcpy2D(h->iiM, sizeof(float) * ldm, M, sizeof(float) * ld, sizeof(float) * n_items, n_items, hipMemcpyDefault));
+    h->ii_ld = ldm;
+    h->ii_chunks = (int)((n_items + chunk - 1) / chunk);
+    int rc = set_col_scale(h, col_scale, n_items, (int64_t)h->ii_chunks * chunk);
+    if (rc) return rc;
+    h->n_items = n_items; h->n_users = 0; h->mode = MODE_ITEM_DENSE;
+    return IFR_OK;
+}
+
+int ifr_set_item_matrix_csr(ifr_handle h, const int64_t *indptr, const int32_t *indices, const float *values,
+                            int64_t n_items, int64_t nnz, const float *col_scale)
+{
+    if (!h) return IFR_ERR_ARG;
+    if (!indptr || n_items <= 0 || nnz < 0 || (nnz > 0 && (!indices || !values)))
+        return fail(h, IFR_ERR_ARG, "ifr_set_item_matrix_csr: null/empty input");
+    if (n_items > (int64_t)1 << 30) return fail(h, IFR_ERR_ARG, "ifr_set_item_matrix_csr: n_items too large");
+    IFR_HIP(h, hipSetDevice(h->device));
+    const int64_t old_items = h->n_items;
+    clear_factor_model(h);
+    clear_item_model(h);
+    h->n_items = old_items;
+    drop_csrs_if_catalogue_changes(h, n_items);
+    h->n_items = 0;
+    std::vector<int64_t> hp;
+    int64_t *d_ptr = nullptr;
+    int rc = copy_csr(h, indptr, indices, n_items, nnz, &d_ptr, &h->ii_idx, &hp);
+    if (rc) { dfree(d_ptr); return rc; }
+    const int chunk = ifr::item_item_chunk(true);
+    const int n_chunks = (int)((n_items + chunk - 1) / chunk);
+    int *d_flags = nullptr;                      // [0] = validation flags, [1] = max |value| bits
+    auto cleanup = [&]() { dfree(d_ptr); dfree(d_flags); };
+    if (hipMalloc((void **)&d_flags, 2 * sizeof(int)) != hipSuccess || hipMemset(d_flags, 0, 2 * sizeof(int)) != hipSuccess ||
+        hipMalloc((void **)&h->ii_val, sizeof(float) * std::max<int64_t>(nnz, 1)) != hipSuccess ||
+        hipMalloc((void **)&h->ii_cptr, sizeof(int64_t) * n_items * (n_chunks + 1)) != hipSuccess) {
+        cleanup(); clear_item_model(h);
+        return fail(h, IFR_ERR_NOMEM, "ifr_set_item_matrix_csr: device allocation failed");
+    }
+    if (nnz > 0 && hipMemcpy(h->ii_val, values, sizeof(float) * nnz, hipMemcpyDefault) != hipSuccess) {
+        cleanup(); clear_item_model(h);
+        return fail(h, IFR_ERR_HIP, "ifr_set_item_matrix_csr: copy of values failed");
+    }
+    int lrc = ifr::launch_validate_csr(d_ptr, h->ii_idx, n_items, (int)n_items, 1, d_flags, 0);
+    uint32_t flags[2] = {0, 0};
+    if (!lrc) lrc = ifr::launch_build_chunk_ptr(d_ptr, h->ii_idx, n_items, n_chunks, chunk, h->ii_cptr, 0);
+    if (!lrc && nnz > 0) lrc = ifr::launch_absmax(h->ii_val, nnz, (uint32_t *)d_flags + 1, 0);
+    if (lrc || hipDeviceSynchronize() != hipSuccess ||
+        hipMemcpy(flags, d_flags, sizeof(flags), hipMemcpyDeviceToHost) != hipSuccess) {
+        cleanup(); clear_item_model(h);
+        return fail(h, IFR_ERR_HIP, "ifr_set_item_matrix_csr: set-up kernels failed");
+    }
+    cleanup();
+    float maxabs;
+    memcpy(&maxabs, &flags[1], sizeof(float));
+    if (flags[0] != 0 || !std::isfinite(maxabs)) {
+        clear_item_model(h);
+        return fail(h, IFR_ERR_ARG, flags[0] & 1 ? "ifr_set_item_matrix_csr: column index outside [0, n_items)"
+                                    : flags[0] & 2 ? "ifr_set_item_matrix_csr: columns of a row are not strictly ascending"
+                                                   : "ifr_set_item_matrix_csr: non-finite value");
+    }
+    h->ii_maxabs = maxabs;
+    h->ii_nnz = nnz;
+    h->ii_chunks = n_chunks;
+    rc = set_col_scale(h, col_scale, n_items, (int64_t)n_chunks * chunk);
+    if (rc) { clear_item_model(h); return rc; }
+    h->n_items = n_items; h->n_users = 0; h->mode = MODE_ITEM_CSR;
+    return IFR_OK;
+}
+
+int ifr_set_history_csr(ifr_handle h, const int64_t *indptr, const int32_t *indices, const float *values,
+                        int64_t n_rows, int64_t nnz)
+{
+    if (!h) return IFR_ERR_ARG;
+    if (h->mode != MODE_ITEM_DENSE && h->mode != MODE_ITEM_CSR)
+        return fail(h, IFR_ERR_STATE, "ifr_set_history_csr: call ifr_set_item_matrix_dense/_csr first");
+    IFR_HIP(h, hipSetDevice(h->device));
+    dfree(h->hs_ptr); dfree(h->hs_idx); dfree(h->hs_val);
+    h->hs_rows = 0; h->hs_nnz = 0; h->hs_l1max = 0.f; h->n_users = 0;
+    if (n_rows <= 0 || !indptr) return IFR_OK;
+    if (nnz < 0 || (nnz > 0 && (!indices || !values))) return fail(h, IFR_ERR_ARG, "ifr_set_history_csr: null indices/values");
+    std::vector<int64_t> hp;
+    int rc = copy_csr(h, indptr, indices, n_rows, nnz, &h->hs_ptr, &h->hs_idx, &hp);
+    if (rc) return rc;
+    int *d_flags = nullptr;
+    bool ok = hipMalloc((void **)&h->hs_val, sizeof(float) * std::max<int64_t>(nnz, 1)) == hipSuccess &&
+              (nnz == 0 || hipMemcpy(h->hs_val, values, sizeof(float) * nnz, hipMemcpyDefault) == hipSuccess) &&
+              hipMalloc((void **)&d_flags, 2 * sizeof(int)) == hipSuccess && hipMemset(d_flags, 0, 2 * sizeof(int)) == hipSuccess;
+    uint32_t flags[2] = {0, 0};
+    ok = ok && ifr::launch_validate_csr(h->hs_ptr, h->hs_idx, n_rows, (int)h->n_items, 0, d_flags, 0) == 0 &&
+         ifr::launch_row_l1_max(h->hs_ptr, h->hs_val, n_rows, (uint32_t *)d_flags + 1, 0) == 0 &&
+         hipDeviceSynchronize() == hipSuccess &&
+         hipMemcpy(flags, d_flags, sizeof(flags), hipMemcpyDeviceToHost) == hipSuccess;
+    dfree(d_flags);
+    float l1;
+    memcpy(&l1, &flags[1], sizeof(float));
+    if (!ok || flags[0] != 0 || !std::isfinite(l1)) {
+        dfree(h->hs_ptr); dfree(h->hs_idx); dfree(h->hs_val);
+        return fail(h, ok ? IFR_ERR_ARG : IFR_ERR_HIP,
+                    !ok ? "ifr_set_history_csr: device set-up failed"
+                        : flags[0] ? "ifr_set_history_csr: item index outside [0, n_items)" : "ifr_set_history_csr: non-finite weight");
+    }
+    h->hs_rows = n_rows; h->hs_nnz = nnz; h->hs_l1max = l1; h->n_users = n_rows;
+    return IFR_OK;
+}
+
+int ifr_item_fixed_point_shift(ifr_handle h, int *shift)
+{
+    if (!h || !shift) return IFR_ERR_ARG;
+    if (h->mode != MODE_ITEM_CSR || !h->hs_ptr) return fail(h, IFR_ERR_STATE, "ifr_item_fixed_point_shift: needs a CSR item matrix and histories");
+    *shift = fixed_point_shift(h);
+    return IFR_OK;
+}
+
+// item-item launch shared by ifr_rank_topk / ifr_score_dense
+static int item_item_params(ifr_handle h, const int32_t *user_ids, int64_t n, ifr::ItemItemParams *p)
+{
+    if (!h->hs_ptr) return fail(h, IFR_ERR_STATE, "item-item model: histories not set (ifr_set_history_csr)");
+    memset(p, 0, sizeof(*p));
+    p->M = h->iiM; p->ldm = h->ii_ld;
+    p->cptr = h->ii_cptr; p->m_idx = h->ii_idx; p->m_val = h->ii_val;
+    p->fx_shift = h->mode == MODE_ITEM_CSR ? fixed_point_shift(h) : 0;
+    p->pen = h->ii_pen;
+    p->h_ptr = h->hs_ptr; p->h_idx = h->hs_idx; p->h_val = h->hs_val; p->h_rows = h->hs_rows;
+    p->user_ids = user_ids; p->n = n; p->n_items = (int)h->n_items; p->n_chunks = h->ii_chunks;
+    p->ex_ptr = h->ex_ptr; p->ex_idx = h->ex_idx; p->ex_rows = h->ex_rows;
+    return IFR_OK;
+}
+
+static int prof_begin(ifr_handle h, hipStream_t s, std::pair<hipEvent_t, hipEvent_t> *ev)
+{
+    if (!h->prof) return IFR_OK;
+    if (!h->ev_free.empty()) { *ev = h->ev_free.back(); h->ev_free.pop_back(); }
+    else { IFR_HIP(h, hipEventCreate(&ev->first)); IFR_HIP(h, hipEventCreate(&ev->second)); }
+    IFR_HIP(h, hipEventRecord(ev->first, s));
+    return IFR_OK;
+}
+
+static int prof_end(ifr_handle h, hipStream_t s, const std::pair<hipEvent_t, hipEvent_t> &ev, double pairs)
+{
+    if (!h->prof) return IFR_OK;
+    IFR_HIP(h, hipEventRecord(ev.second, s));
+    h->ev_used.push_back(ev);
+    h->prof_pairs += pairs;
+    return IFR_OK;
+}
+
+static int rank_topk_item_item(ifr_handle h, const int32_t *user_ids, int64_t n, int K, int KL, int32_t *out_ids,
+                               float *out_scores, hipStream_t s)
+{
+    ifr::ItemItemParams p;
+    int rc = item_item_params(h, user_ids, n, &p);
+    if (rc) return rc;
+    if ((int64_t)p.n_chunks * n > 0x7fffffff) return fail(h, IFR_ERR_ARG, "ifr_rank_topk: batch too large, split the user list");
+    const size_t entries = (size_t)n * p.n_chunks * KL;
+    rc = grow(h, &h->ws_part, &h->ws_part_bytes, entries * 8);
+    if (rc) return rc;
+    p.K = K; p.KL = KL;
+    p.part_scores = (float *)h->ws_part;
+    p.part_ids = (int32_t *)((char *)h->ws_part + entries * 4);
+    std::pair<hipEvent_t, hipEvent_t> ev;
+    rc = prof_begin(h, s, &ev);
+    if (rc) return rc;
+    if (ifr::launch_item_item(p, h->mode == MODE_ITEM_CSR, true, s)) return fail(h, IFR_ERR_HIP, "ifr_rank_topk: item-item launch failed");
+    rc = prof_end(h, s, ev, (double)n * (double)h->n_items);
+    if (rc) return rc;
+    const size_t smem = (size_t)p.n_chunks * KL * 8;
+    if (smem > 60000) return fail(h, IFR_ERR_ARG, "ifr_rank_topk: catalogue too large for the merge kernel");
+    if (KL == 16)
+        hipLaunchKernelGGL((ifr::merge_topk_kernel<16>), dim3((unsigned)n), dim3(64), smem, s, p.part_scores, p.part_ids, n,
+                           p.n_chunks, K, out_ids, out_scores);
+    else
+        hipLaunchKernelGGL((ifr::merge_topk_kernel<32>), dim3((unsigned)n), dim3(64), smem, s, p.part_scores, p.part_ids, n,
+                           p.n_chunks, K, out_ids, out_scores);
+    IFR_HIP(h, hipGetLastError());
+    return IFR_OK;
+}
+
 int ifr_rank_topk(ifr_handle h, const int32_t *user_ids, int64_t n, int K, int32_t *out_ids, float *out_scores, void *stream)
 {
     if (!h) return IFR_ERR_ARG;
-    if (!h->U) return fail(h, IFR_ERR_STATE, "ifr_rank_topk: factors not set");
+    if (h->mode == MODE_NONE) return fail(h, IFR_ERR_STATE, "ifr_rank_topk: no model set");
     if (n == 0) return IFR_OK;
     if (!user_ids || !out_ids || !out_scores || n < 0) return fail(h, IFR_ERR_ARG, "ifr_rank_topk: null/negative argument");
     if (K < 1 || K > IFR_MAX_TOPK) return fail(h, IFR_ERR_ARG, "ifr_rank_topk: K must be in [1, 32]");
     IFR_HIP(h, hipSetDevice(h->device));
     hipStream_t s = (hipStream_t)stream;
     const int KL = K <= 16 ? 16 : 32;
+    if (h->mode != MODE_FACTOR) return rank_topk_item_item(h, user_ids, n, K, KL, out_ids, out_scores, s);
     int chunk_tiles, n_chunks;
     pick_chunks(h, n, &chunk_tiles, &n_chunks);
     const int64_t n_ut = (n + ifr::USERS_PER_BLOCK - 1) / ifr::USERS_PER_BLOCK;
@@ -399,10 +663,20 @@ int ifr_rank_items(ifr_handle h, const float *scores, int64_t n_scores, const in
 int ifr_score_dense(ifr_handle h, const int32_t *user_ids, int64_t n, float *out, int64_t ld, void *stream)
 {
     if (!h) return IFR_ERR_ARG;
-    if (!h->U) return fail(h, IFR_ERR_STATE, "ifr_score_dense: factors not set");
+    if (h->mode == MODE_NONE) return fail(h, IFR_ERR_STATE, "ifr_score_dense: no model set");
     if (n == 0) return IFR_OK;
     if (!user_ids || !out || n < 0 || ld < h->n_items) return fail(h, IFR_ERR_ARG, "ifr_score_dense: null argument or ld < n_items");
     IFR_HIP(h, hipSetDevice(h->device));
+    if (h->mode != MODE_FACTOR) {
+        ifr::ItemItemParams ip;
+        int rc = item_item_params(h, user_ids, n, &ip);
+        if (rc) return rc;
+        if ((int64_t)ip.n_chunks * n > 0x7fffffff) return fail(h, IFR_ERR_ARG, "ifr_score_dense: batch too large");
+        ip.out = out; ip.ld = ld;
+        if (ifr::launch_item_item(ip, h->mode == MODE_ITEM_CSR, false, (hipStream_t)stream))
+            return fail(h, IFR_ERR_HIP, "ifr_score_dense: item-item launch failed");
+        return IFR_OK;
+    }
     int chunk_tiles, n_chunks;
     pick_chunks(h, n, &chunk_tiles, &n_chunks);
     const int64_t n_ut = (n + ifr::USERS_PER_BLOCK - 1) / ifr::USERS_PER_BLOCK;
@@ -478,7 +752,7 @@ int ifr_profile_read(ifr_handle h, double *kernel_ms, int64_t *launches, double 
 int ifr_factor_chain_order(ifr_handle h, int32_t *perm, int *n)
 {
     if (!h || !perm || !n) return IFR_ERR_ARG;
-    if (h->KD == 0) return fail(h, IFR_ERR_STATE, "ifr_factor_chain_order: factors not set");
+    if (h->mode != MODE_FACTOR || h->KD == 0) return fail(h, IFR_ERR_STATE, "ifr_factor_chain_order: factors not set");
     // MFMA step 4g+e multiplies k = 8g+e (lanes 0-31) then k = 8g+4+e (lanes 32-63).
     int t = 0;
     for (int g = 0; g < h->KD / 8; ++g)

@@ -1,0 +1,44 @@
+// ifr_itemitem.h -- launch interface of the item-item kernels (ifr_itemitem.hip) used by ifr_api.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ifr {
+
+struct ItemItemParams {
+    const float *M;              // dense: [n_items][ldm]
+    int64_t ldm;                 //        row stride, multiple of II_PASS
+    const int64_t *cptr;         // sparse: [n_items][n_chunks + 1] entry positions per item chunk
+    const int32_t *m_idx;        //         column of every entry
+    const float *m_val;
+    int fx_shift;                //         fixed-point scale 2^fx_shift
+    const float *pen;            // [>= n_chunks * chunk] column scale or null
+    const int64_t *h_ptr;        // history CSR
+    const int32_t *h_idx;
+    const float *h_val;
+    int64_t h_rows;
+    const int32_t *user_ids;
+    int64_t n;
+    int n_items;
+    int n_chunks;
+    const int64_t *ex_ptr;       // raw exclusion CSR (may be null)
+    const int32_t *ex_idx;
+    int64_t ex_rows;
+    int K, KL;
+    float *part_scores;          // [n][n_chunks][KL]   (TOPK)
+    int32_t *part_ids;
+    float *out;                  // [n][ld]             (dense rows)
+    int64_t ld;
+};
+
+int launch_item_item(const ItemItemParams &p, bool sparse, bool topk, hipStream_t stream);
+int item_item_chunk(bool sparse);
+int item_item_pass();
+int launch_validate_csr(const int64_t *ptr, const int32_t *idx, int64_t n_rows, int n_cols, int need_sorted, int *bad,
+                        hipStream_t s);
+int launch_build_chunk_ptr(const int64_t *ptr, const int32_t *idx, int64_t n_rows, int n_chunks, int chunk, int64_t *cptr,
+                           hipStream_t s);
+int launch_absmax(const float *x, int64_t n, uint32_t *out, hipStream_t s);
+int launch_row_l1_max(const int64_t *ptr, const float *val, int64_t n_rows, uint32_t *out, hipStream_t s);
+
+}  // namespace ifr

@@ -44,6 +44,7 @@ class HipScorer:
         self.n_users = self.n_items = self.k = 0
         self.has_exclusions = False
         self.has_truth = False
+        self.item_model = None          # None (dot-product factors) | "dense" | "csr"
 
     # ------------------------------------------------------------------ plumbing
     def close(self):
@@ -100,7 +101,60 @@ class HipScorer:
         pib, kib = self._any_ptr(ibase, np.float32)
         self._check(self._lib.ifr_set_factors(self._h, pu, n_users, pv, n_items, k, pub, pib))
         self.n_users, self.n_items, self.k = int(n_users), int(n_items), int(k)
+        self.item_model = None
         del ku, kv, kub, kib
+
+    def set_item_matrix_dense(self, M, col_scale=None):
+        """Item-item model with a dense M [I, I] (EASE's B, or a dense RP3-beta W); NumPy or torch."""
+        n_items = int(M.shape[0])
+        if M.shape[1] != n_items:
+            raise ValueError("the item matrix must be square")
+        torch = _torch()
+        if isinstance(M, torch.Tensor):
+            M = M if M.dtype == torch.float32 else M.float()
+            ld = M.stride(0) if M.stride(1) == 1 else None
+            if ld is None:
+                M = M.contiguous()
+                ld = M.stride(0)
+            pm, km = ctypes.c_void_p(M.data_ptr()), M
+        else:
+            M = np.ascontiguousarray(M, np.float32)
+            ld = n_items
+            pm, km = _host_ptr(M), M
+        pc, kc = self._any_ptr(col_scale, np.float32)
+        self._check(self._lib.ifr_set_item_matrix_dense(self._h, pm, n_items, int(ld), pc))
+        self.n_items, self.k, self.n_users = n_items, 0, 0
+        self.item_model = "dense"
+        self.has_exclusions = False
+        del km, kc
+
+    def set_item_matrix_csr(self, indptr, indices, values, n_items, col_scale=None):
+        """Item-item model with a sparse M (CSR rows, strictly ascending columns)."""
+        pp, kp = self._any_ptr(indptr, np.int64)
+        pi, ki = self._any_ptr(indices, np.int32)
+        pv, kv = self._any_ptr(values, np.float32)
+        pc, kc = self._any_ptr(col_scale, np.float32)
+        self._check(self._lib.ifr_set_item_matrix_csr(self._h, pp, pi, pv, int(n_items), len(indices), pc))
+        self.n_items, self.k, self.n_users = int(n_items), 0, 0
+        self.item_model = "csr"
+        self.has_exclusions = False
+        del kp, ki, kv, kc
+
+    def set_history_csr(self, indptr, indices, values):
+        """Per-user histories (items, weights) of an item-item model."""
+        pp, kp = self._any_ptr(indptr, np.int64)
+        pi, ki = self._any_ptr(indices, np.int32)
+        pv, kv = self._any_ptr(values, np.float32)
+        n_rows = len(indptr) - 1
+        self._check(self._lib.ifr_set_history_csr(self._h, pp, pi, pv, n_rows, len(indices)))
+        # any user index is valid for an item-item model: users past the last row have no history
+        self.n_users = 2 ** 31 - 1
+        del kp, ki, kv
+
+    def item_fixed_point_shift(self):
+        sh = ctypes.c_int(0)
+        self._check(self._lib.ifr_item_fixed_point_shift(self._h, ctypes.byref(sh)))
+        return sh.value
 
     def set_exclusion_csr(self, indptr, indices):
         pp, kp = self._any_ptr(indptr, np.int64)

@@ -126,25 +126,29 @@ class HipScoringMixin:
         eng = getattr(self, "_hip", None)
         if eng is None:
             from .engine import HipScorer
-            U, V, ubase, ibase = self._hip_factor_params()
-            U = np.ascontiguousarray(U, np.float32)
-            # all-zero rows for every user index the model has no factors for (up to total_users)
-            # plus one spare: users whose user term is dropped, or who cannot be scored, map there
-            n_ext = max(int(self.total_users or 0), U.shape[0]) + 1
-            Ue = np.zeros((n_ext, U.shape[1]), np.float32)
-            Ue[: U.shape[0]] = U
-            ube = None
-            if ubase is not None:
-                ube = np.zeros(n_ext, np.float32)
-                ube[: len(ubase)] = np.asarray(ubase, np.float32)
-            if ube is None and ibase is not None:
-                ube = np.zeros(len(Ue), np.float32)
             eng = HipScorer(self.hip_device)
-            eng.set_factors(Ue, np.ascontiguousarray(V, np.float32), ube,
-                            None if ibase is None else np.ascontiguousarray(ibase, np.float32))
+            self._hip_setup(eng)
             self._hip = eng
-            self._hip_zero_row = n_ext - 1
         return eng
+
+    def _hip_setup(self, eng):
+        """Upload the model to a fresh engine (dot-product models; item-item models override)."""
+        U, V, ubase, ibase = self._hip_factor_params()
+        U = np.ascontiguousarray(U, np.float32)
+        # all-zero rows for every user index the model has no factors for (up to total_users)
+        # plus one spare: users whose user term is dropped, or who cannot be scored, map there
+        n_ext = max(int(self.total_users or 0), U.shape[0]) + 1
+        Ue = np.zeros((n_ext, U.shape[1]), np.float32)
+        Ue[: U.shape[0]] = U
+        ube = None
+        if ubase is not None:
+            ube = np.zeros(n_ext, np.float32)
+            ube[: len(ubase)] = np.asarray(ubase, np.float32)
+        if ube is None and ibase is not None:
+            ube = np.zeros(len(Ue), np.float32)
+        eng.set_factors(Ue, np.ascontiguousarray(V, np.float32), ube,
+                        None if ibase is None else np.ascontiguousarray(ibase, np.float32))
+        self._hip_zero_row = n_ext - 1
 
     def hip_invalidate(self):
         """Drop the device copy (call after the parameters change)."""
@@ -163,8 +167,11 @@ class HipScoringMixin:
         eng = self._hip_engine()
         dense = eng.score_dense(np.asarray([row], np.int32))[0]
         if item_idx is None:
-            return dense.cpu().numpy().astype(self.score_dtype, copy=False)
+            return self._hip_shape_scores(dense.cpu().numpy().astype(self.score_dtype, copy=False))
         return self.score_dtype(dense[int(item_idx)].item())
+
+    def _hip_shape_scores(self, scores):
+        return scores
 
     _hip_item_must_be_known = True
 
@@ -302,6 +309,124 @@ class WMF(HipScoringMixin, RecommenderBase):
         return int(user_idx) if self.knows_user(user_idx) else -1
 
 
+class ItemItemScoringMixin(HipScoringMixin):
+    """score / rank / rank_batch for item-item models: s_u = (x_u . M) * col_scale.
+
+    A concrete class supplies `_hip_item_model() -> (M, histories, col_scale)`: M a dense
+    [I, I] array / tensor or a scipy CSR matrix, histories a scipy CSR [users, I] whose rows hold
+    x_u, col_scale an [I] array or None.  The reference computes these models in fp64
+    ("Precision mix"); the HIP path scores in fp32 (dense M) or in 64-bit
+    fixed point (CSR M) and returns float64 arrays like the reference."""
+
+    score_dtype = np.float64
+
+    def _hip_setup(self, eng):
+        import scipy.sparse as sp
+        M, hist, col_scale = self._hip_item_model()
+        if sp.issparse(M):
+            M = sp.csr_matrix(M)
+            M.sort_indices()
+            eng.set_item_matrix_csr(M.indptr.astype(np.int64), M.indices.astype(np.int32),
+                                    M.data.astype(np.float32), M.shape[0], col_scale)
+        else:
+            eng.set_item_matrix_dense(M, col_scale)
+        hist = sp.csr_matrix(hist)
+        eng.set_history_csr(hist.indptr.astype(np.int64), hist.indices.astype(np.int32), hist.data.astype(np.float32))
+        self._hip_zero_row = max(int(self.total_users or 0), hist.shape[0])     # a user without history
+
+    def _hip_user_row(self, user_idx):
+        return int(user_idx) if self.knows_user(user_idx) else -1
+
+
+class EASE(ItemItemScoringMixin, RecommenderBase):
+    """cornac.models.EASE scoring (cornac/models/ease/recom_ease.py:99-126): s = X[u, :] . B with
+    X = train_set.matrix (:75).  init_params: {'B': [I, I]}; without it `fit` builds B with the
+    reference's closed form (:78-95) on the host -- a one-off model build step outside the hot
+    path."""
+
+    def __init__(self, name="EASEᴿ", lamb=500, posB=True, trainable=True, verbose=True, seed=None, B=None, U=None,
+                 init_params=None, **kwargs):
+        RecommenderBase.__init__(self, name=name, trainable=trainable, verbose=verbose)
+        self.lamb, self.posB, self.seed = lamb, posB, seed
+        self.B = B if B is not None else (init_params or {}).get("B")
+        self.U = U
+
+    def fit(self, train_set, val_set=None):
+        RecommenderBase.fit(self, train_set, val_set)
+        self.U = train_set.matrix                                   # recom_ease.py:75
+        if self.B is None:
+            if not self.trainable:
+                raise ValueError("EASE(trainable=False) needs init_params={'B': ...}")
+            G = self.U.T.dot(self.U).toarray()                      # :78
+            di = np.diag_indices(G.shape[0])
+            G[di] = G.diagonal() + self.lamb
+            P = np.linalg.inv(G)
+            B = P / (-np.diag(P))
+            B[di] = 0.0
+            if self.posB:
+                B[B < 0] = 0
+            self.B = B
+        self.hip_invalidate()
+        return self
+
+    def _hip_item_model(self):
+        return self.B, self.U, None
+
+    def _hip_shape_scores(self, scores):
+        return scores.reshape(1, -1)        # the reference returns the (1, I) product of a sparse row (:124)
+
+
+class RP3_Beta(ItemItemScoringMixin, RecommenderBase):
+    """cornac.models.RP3_Beta scoring (cornac/models/rp3_beta/recom_rp3beta.py:99-131,
+    graph_recommender.py:87-117): s = P3[u, items] / deg(item)^beta, evaluated in item-item form
+    s = (P_ui[u, :] . W) * deg^-beta with W = P_iu . P_ui, so the (U+I)^2 cube P3 is never built.
+    `fit` builds P_ui, W and the degrees from the binarised train matrix (rating > 0, :76) with
+    SciPy on the host: the model build step, outside the hot path.
+    item_matrix: "csr" | "dense" | "auto" (dense below 8192 items)."""
+
+    def __init__(self, beta=0.7, name="RP3_beta", trainable=True, verbose=False, item_matrix="auto", **kwargs):
+        RecommenderBase.__init__(self, name=name, trainable=trainable, verbose=verbose)
+        self.beta = beta
+        self.item_matrix = item_matrix
+        self.P_ui = self.W = self.item_degrees = None
+
+    def fit(self, train_set, val_set=None):
+        import scipy.sparse as sp
+        RecommenderBase.fit(self, train_set)
+        A = sp.csr_matrix(train_set.csr_matrix, dtype=np.float64)
+        A.data[:] = (A.data > 0).astype(np.float64)                  # recom_rp3beta.py:73-93
+        A.eliminate_zeros()
+        du = np.asarray(A.sum(axis=1)).ravel()
+        di = np.asarray(A.sum(axis=0)).ravel()
+        du[du == 0] = 0.0001                                          # graph_recommender.py:54
+        di[di == 0] = 0.0001
+        self.P_ui = (sp.diags(1.0 / du) @ A).tocsr()
+        P_iu = (sp.diags(1.0 / di) @ A.T).tocsr()
+        self.W = (P_iu @ self.P_ui).tocsr()
+        self.W.sort_indices()
+        self.item_degrees = A.getnnz(axis=0).astype(np.int64)        # :67
+        self.hip_invalidate()
+        return self
+
+    def _hip_item_model(self):
+        # the reference keeps the degrees in an int array, so its 0.0001 guard stores 0 and a
+        # zero-degree item scores 0 * inf = nan (graph_recommender.py:107-115); same here
+        with np.errstate(divide="ignore"):
+            pen = (1.0 / (self.item_degrees.astype(np.float64) ** self.beta)).astype(np.float32)
+        mode = self.item_matrix
+        if mode == "auto":
+            mode = "dense" if self.W.shape[0] <= 8192 else "csr"
+        M = self.W.astype(np.float32)
+        if mode == "dense":
+            M = M.toarray()
+        return M, self.P_ui.astype(np.float32), pen
+
+    def rank(self, user_idx, item_indices=None, k=-1, **kwargs):
+        if self.is_unknown_user(user_idx):                            # recom_rp3beta.py:155-158: not caught
+            raise ScoreException("Can't make score prediction for (user_id=%d)" % user_idx)
+        return HipScoringMixin.rank(self, user_idx, item_indices, k, **kwargs)
+
+
 def wrap_reference_model(model, device=0):
     """Give a fitted reference model (cornac.models.BPR / MF / WMF instance) the HIP scoring path
     without touching its class: returns a facade that shares its parameter arrays and fit
@@ -316,6 +441,11 @@ def wrap_reference_model(model, device=0):
                               "mu": model.global_mean})
     elif name == "WMF":
         out = WMF(name=model.name, k=model.k, init_params={"U": model.U, "V": model.V})
+    elif name == "EASE":
+        out = EASE(name=model.name, lamb=model.lamb, posB=model.posB, B=model.B, U=model.U, trainable=False)
+    elif name == "RP3_Beta":
+        out = RP3_Beta(beta=model.beta, name=model.name)
+        out.fit(model.train_set)
     else:
         raise TypeError(f"no HIP scoring facade for {name}")
     for attr in ("num_users", "num_items", "uid_map", "iid_map", "min_rating", "max_rating", "global_mean",

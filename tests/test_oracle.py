@@ -234,3 +234,77 @@ def test_c_twin_matches_numpy(toy):
     b = orc.c_score_factor(d["bpr_U"][3], d["bpr_V"], d["bpr_Bi"], 0.0, kperm)
     np.testing.assert_allclose(a, b, rtol=0, atol=1e-6)
     assert (ids[:, 0] >= 0).all()
+
+
+# ----------------------------------------------------------------- item-item restatements (EASE, RP3-beta)
+def _hist(csr, u):
+    return csr.indices[csr.indptr[u]: csr.indptr[u + 1]], csr.data[csr.indptr[u]: csr.indptr[u + 1]]
+
+
+def _close(got, ref, tol):
+    ok = np.isfinite(ref)
+    scale = np.maximum(np.abs(ref), np.abs(ref[ok]).max() * 1e-3)
+    assert np.all(np.abs(got[ok] - ref[ok]) <= tol * scale[ok])
+
+
+def test_item_dense_restatement_against_reference_ease(toy):
+    """fp32 fma chain in history order (what the HIP dense kernel computes) vs EASE.score of the reference."""
+    d = toy
+    X = _csr(d, "train")
+    B32 = d["ease_B"].astype(np.float32)
+    for u, ref in zip(d["ease__score_users"], d["ease__score_vecs"]):
+        hi, hv = _hist(X, int(u))
+        got = orc.c_score_item_dense(B32, hi, hv)
+        _close(got.astype(np.float64), ref, 1e-5)
+
+
+def test_item_restatements_against_reference_rp3(toy):
+    """Dense chain and fixed-point CSR accumulation vs RP3_Beta.score of the reference; the two
+    forms agree with each other to fp32 rounding, and the fixed-point sum is order-free."""
+    d = toy
+    X = _csr(d, "train")
+    A_bin = sp.csr_matrix((X > 0).astype(np.float64))
+    P32, W32, pen = orc.rp3_model_arrays(A_bin, float(d["rp3_beta"]))
+    Wd = W32.toarray()
+    shift = orc.item_fixed_point_shift(W32.data, P32.indptr, P32.data)
+    assert 40 < shift < 80
+    for u, ref in zip(d["rp3__score_users"], d["rp3__score_vecs"]):
+        hi, hv = _hist(P32, int(u))
+        dense = orc.c_score_item_dense(Wd, hi, hv, pen)
+        sparse = orc.c_score_item_csr(W32.indptr, W32.indices, W32.data, W32.shape[0], hi, hv, shift, pen)
+        _close(dense.astype(np.float64), ref, 1e-5)
+        _close(sparse.astype(np.float64), ref, 1e-5)
+        np.testing.assert_allclose(dense, sparse, rtol=2e-6, atol=1e-12)
+        perm = np.random.default_rng(int(u)).permutation(len(hi))
+        again = orc.c_score_item_csr(W32.indptr, W32.indices, W32.data, W32.shape[0], hi[perm], hv[perm], shift, pen)
+        np.testing.assert_array_equal(sparse, again)
+    with pytest.raises(OverflowError):
+        orc.c_score_item_csr(W32.indptr, W32.indices, W32.data, W32.shape[0], hi, hv, shift + 12, pen)
+
+
+def test_c_ranking_eval_item_matches_numpy(toy):
+    """The C per-user loop for item-item models against the NumPy restatement driven by the same scores."""
+    d = toy
+    ni = int(d["num_items"])
+    train, test, val = _csr(d, "train"), _csr(d, "test"), _csr(d, "val")
+    thr = float(d["rating_threshold"])
+    B32 = d["ease_B"].astype(np.float32)
+    users = d["ease__users"][:60]
+    from recommenders_amd.eval import build_eval_csrs
+    truth, excl, _ = build_eval_csrs(train, test, val, thr, ni, test.shape[0])
+    X = sp.csr_matrix(train, dtype=np.float32)
+    ids, sc, met, ev = orc.c_ranking_eval_item(B32, None, 0, ni, None, X.indptr, X.indices, X.data, users,
+                                               excl.indptr, excl.indices, truth.indptr, truth.indices,
+                                               [10, 5], True, 20, n_threads=2)
+    assert ev.all()
+    for r, u in enumerate(users):
+        hi, hv = _hist(X, int(u))
+        s = orc.c_score_item_dense(B32, hi, hv)
+        item_indices, gt_pos, gt_neg = orc.eval_sets(train, test, val, int(u), thr, ni, test.shape[1], True)
+        rank = orc.canonical_rank(item_indices, s[item_indices])
+        np.testing.assert_array_equal(ids[r], rank[:20])
+        np.testing.assert_array_equal(sc[r], s[rank[:20]])
+        exp = [orc.ndcg(gt_pos, rank, 10), orc.recall(gt_pos, rank, 10), orc.precision(gt_pos, rank, 10),
+               orc.ndcg(gt_pos, rank, 5), orc.recall(gt_pos, rank, 5), orc.precision(gt_pos, rank, 5),
+               orc.auc(item_indices, s[item_indices], gt_pos, gt_neg)]
+        np.testing.assert_allclose(met[r], exp, rtol=0, atol=1e-12)
