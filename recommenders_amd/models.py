@@ -393,7 +393,7 @@ class RP3_Beta(ItemItemScoringMixin, RecommenderBase):
     def fit(self, train_set, val_set=None):
         import scipy.sparse as sp
         RecommenderBase.fit(self, train_set)
-        A = sp.csr_matrix(train_set.csr_matrix, dtype=np.float64)
+        A = sp.csr_matrix(train_set.csr_matrix, dtype=np.float64, copy=True)   # never write into the data set
         A.data[:] = (A.data > 0).astype(np.float64)                  # recom_rp3beta.py:73-93
         A.eliminate_zeros()
         du = np.asarray(A.sum(axis=1)).ravel()
