@@ -23,6 +23,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+PEAK_HBM_GBS = 8000.0            # same guide: HBM3E ~8 TB/s
 TOPK = 10
 
 
@@ -41,6 +42,35 @@ def cpu_baseline(w, n_sample, chain):
     return dict(value=n_sample / dt, unit="users/s", cores=threads, kind="port",
                 sample=f"{n_sample} users x {w['n_items']} items of the same workload, "
                        f"oracle/ifr_oracle.c orc_ranking_eval_factor, {dt:.1f} s"), ids, met, ev
+
+
+def cpu_baseline_item(w, n_sample, shift):
+    """The same per-user loop for an item-item model (oracle/ifr_oracle.c orc_ranking_eval_item)."""
+    from oracle import oracle as orc
+    threads = min(16, os.cpu_count() or 1)
+    users = np.arange(n_sample, dtype=np.int32)
+    M = w["M"]
+    if M is not None and not isinstance(M, np.ndarray):
+        M = M.cpu().numpy()
+    m_csr = None if w["m_ptr"] is None else (w["m_ptr"], w["m_idx"], w["m_val"])
+    t = time.perf_counter()
+    ids, sc, met, ev = orc.c_ranking_eval_item(M, m_csr, shift, w["n_items"], w["col_scale"], w["h_ptr"], w["h_idx"],
+                                               w["h_val"], users, w["excl_ptr"], w["excl_idx"], w["truth_ptr"],
+                                               w["truth_idx"], [TOPK], False, TOPK, n_threads=threads)
+    dt = time.perf_counter() - t
+    return dict(value=n_sample / dt, unit="users/s", cores=threads, kind="port",
+                sample=f"{n_sample} users x {w['n_items']} items of the same workload, "
+                       f"oracle/ifr_oracle.c orc_ranking_eval_item, {dt:.1f} s"), ids, met, ev
+
+
+def item_algorithmic_bytes(w):
+    """dense M: 4*I bytes per history entry; CSR M: 8 bytes per nonzero of every
+    history row plus the 4*I-byte score vector per user."""
+    n, I = w["n_users"], w["n_items"]
+    if w["M"] is not None:
+        return 4.0 * I * float(w["h_ptr"][n])
+    row_nnz = np.diff(w["m_ptr"])
+    return 8.0 * float(row_nnz[w["h_idx"][: w["h_ptr"][n]]].sum()) + 4.0 * I * n
 
 
 def cpu_strong(w, n_sample):
@@ -77,13 +107,15 @@ def main():
     ap.add_argument("--config", default="c2_wmf_ml20m")
     ap.add_argument("--users", type=int, default=None, help="override users per rank (debug only)")
     ap.add_argument("--items", type=int, default=None, help="override catalogue size (debug only)")
-    ap.add_argument("--cpu-sample", type=int, default=65536)
+    ap.add_argument("--cpu-sample", type=int, default=None, help="users in the CPU baseline sample")
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
 
     import torch
     import torch.distributed as dist
     from recommenders_amd import HipScorer, synth
+    if args.cpu_sample is None:
+        args.cpu_sample = 65536 if args.config == "c2_wmf_ml20m" else (4096 if args.config == "c3_mf_shard" else 16384)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -94,11 +126,21 @@ def main():
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
 
-    # each rank owns one user shard of the configured size (weak scaling); item factors replicated
-    w = synth.make(args.config, n_users=args.users, n_items=args.items,
-                   seed=synth.CONFIGS[args.config][4] + 1000 * rank)
+    # each rank owns one user shard of the configured size (weak scaling); item-side parameters replicated
+    item_model = args.config in synth.ITEM_CONFIGS
     sc = HipScorer(local)
-    sc.set_factors(w["U"], w["V"], w["ubase"], w["ibase"])
+    if item_model:
+        w = synth.make_item(args.config, n_users=args.users, n_items=args.items,
+                            seed=synth.ITEM_CONFIGS[args.config][3] + 1000 * rank, device=dev)
+        if w["M"] is not None:
+            sc.set_item_matrix_dense(w["M"], w["col_scale"])
+        else:
+            sc.set_item_matrix_csr(w["m_ptr"], w["m_idx"], w["m_val"], w["n_items"], w["col_scale"])
+        sc.set_history_csr(w["h_ptr"], w["h_idx"], w["h_val"])
+    else:
+        w = synth.make(args.config, n_users=args.users, n_items=args.items,
+                       seed=synth.CONFIGS[args.config][4] + 1000 * rank)
+        sc.set_factors(w["U"], w["V"], w["ubase"], w["ibase"])
     sc.set_exclusion_csr(w["excl_ptr"], w["excl_idx"])
     sc.set_truth_csr(w["truth_ptr"], w["truth_idx"])
     n = w["n_users"]
@@ -141,9 +183,34 @@ def main():
 
     if rank == 0:
         sums = sums.cpu().numpy()
-        flops_per_launch = 2.0 * n * w["n_items"] * w["k"]           # 2*I*k per user x users per launch
         avg_ms = kern_ms / max(launches, 1)
-        achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12
+        if item_model:
+            bytes_per_launch = item_algorithmic_bytes(w)
+            achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
+            dense = w["M"] is not None
+            kind = "EASE-style dense item-item B" if dense else "RP3-beta-style sparse item-item W"
+            workload = (f"{args.config}: {kind}, {n} users/GPU x {w['n_items']} items, "
+                        f"{float(w['h_ptr'][n]) / n:.1f} history items/user"
+                        + ("" if dense else f", {int(np.diff(w['m_ptr']).mean())} neighbours/row")
+                        + f", top-{TOPK} + NDCG@{TOPK}/Recall@{TOPK}/Precision@{TOPK}")
+            roof = {"bound": "hbm", "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                    "frac": achieved / PEAK_HBM_GBS, "traffic": None,
+                    "kernel": "item_item_kernel", "avg_launch_ms": avg_ms, "launches": launches,
+                    "bytes_per_launch": bytes_per_launch}
+            cfg = {"workload": workload, "users_per_gpu": n, "items": w["n_items"], "topk": TOPK,
+                   "parallelism": f"users sharded x{world}, item matrix replicated"}
+        else:
+            flops_per_launch = 2.0 * n * w["n_items"] * w["k"]       # 2*I*k per user x users per launch
+            achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12
+            roof = {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": achieved / PEAK_F32_MFMA_TFLOPS,
+                    "traffic": measured_traffic(args.config, n, w["n_items"]),
+                    "kernel": "score_topk_kernel", "avg_launch_ms": avg_ms, "launches": launches,
+                    "flops_per_launch": flops_per_launch}
+            cfg = {"workload": f"{args.config}: dot-product model, {n} users/GPU x {w['n_items']} items, "
+                               f"k={w['k']}, top-{TOPK} + NDCG@{TOPK}/Recall@{TOPK}/Precision@{TOPK}",
+                   "users_per_gpu": n, "items": w["n_items"], "k": w["k"], "topk": TOPK,
+                   "parallelism": f"users sharded x{world}, item factors replicated"}
         out = {
             "metric": "users ranked/sec (full-catalogue top-10 + NDCG/Recall)",
             "value": world * n * args.steps / dt,
@@ -157,24 +224,21 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": f"{args.config}: WMF-style dot-product model, {n} users/GPU x {w['n_items']} items, "
-                                   f"k={w['k']}, top-{TOPK} + NDCG@{TOPK}/Recall@{TOPK}/Precision@{TOPK}",
-                       "users_per_gpu": n, "items": w["n_items"], "k": w["k"], "topk": TOPK,
-                       "parallelism": f"users sharded x{world}, item factors replicated"},
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_F32_MFMA_TFLOPS,
-                         "traffic": measured_traffic(args.config, n, w["n_items"]),
-                         "kernel": "score_topk_kernel", "avg_launch_ms": avg_ms, "launches": launches,
-                         "flops_per_launch": flops_per_launch},
+            "config": cfg,
+            "roofline": roof,
             "eval": {"ndcg@10": sums[0] / sums[-1], "recall@10": sums[1] / sums[-1],
                      "precision@10": sums[2] / sums[-1], "n_evaluated": float(sums[-1])},
         }
         if world == 1 and not args.no_cpu:
-            base, o_ids, _, _ = cpu_baseline(w, min(args.cpu_sample, n), sc.chain_order())
-            out["cpu_baseline"] = base
             m = min(args.cpu_sample, n)
+            if item_model:
+                shift = sc.item_fixed_point_shift() if w["M"] is None else 0
+                base, o_ids, _, _ = cpu_baseline_item(w, m, shift)
+            else:
+                base, o_ids, _, _ = cpu_baseline(w, m, sc.chain_order())
+                out["cpu_baseline_strong"] = cpu_strong(w, min(2048, n))
+            out["cpu_baseline"] = base
             out["parity_on_cpu_sample"] = {"users": m, "top10_ids_equal": bool((h_ids[:m].numpy() == o_ids).all())}
-            out["cpu_baseline_strong"] = cpu_strong(w, min(2048, n))
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

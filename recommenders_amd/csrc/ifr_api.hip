@@ -506,7 +506,7 @@ static int rank_topk_item_item(ifr_handle h, const int32_t *user_ids, int64_t n,
     ifr::ItemItemParams p;
     int rc = item_item_params(h, user_ids, n, &p);
     if (rc) return rc;
-    if ((int64_t)p.n_chunks * n > 0x7fffffff) return fail(h, IFR_ERR_ARG, "ifr_rank_topk: batch too large, split the user list");
+    if (n > (int64_t)1 << 24) return fail(h, IFR_ERR_ARG, "ifr_rank_topk: more than 2^24 users in one call, split the user list");
     const size_t entries = (size_t)n * p.n_chunks * KL;
     rc = grow(h, &h->ws_part, &h->ws_part_bytes, entries * 8);
     if (rc) return rc;
@@ -546,7 +546,7 @@ int ifr_rank_topk(ifr_handle h, const int32_t *user_ids, int64_t n, int K, int32
     pick_chunks(h, n, &chunk_tiles, &n_chunks);
     const int64_t n_ut = (n + ifr::USERS_PER_BLOCK - 1) / ifr::USERS_PER_BLOCK;
     const int64_t grid = n_ut * n_chunks;
-    if (grid > 0x7fffffff) return fail(h, IFR_ERR_ARG, "ifr_rank_topk: batch too large, split the user list");
+    if (grid > (int64_t)0xffffffffu / ifr::BLOCK) return fail(h, IFR_ERR_ARG, "ifr_rank_topk: batch too large, split the user list");
     const size_t entries = (size_t)n * n_chunks * 2 * KL;
     const size_t lb_bytes = (size_t)n_ut * ifr::USERS_PER_BLOCK * sizeof(uint32_t);
     int rc = grow(h, &h->ws_part, &h->ws_part_bytes, entries * 8 + lb_bytes);
@@ -671,7 +671,7 @@ int ifr_score_dense(ifr_handle h, const int32_t *user_ids, int64_t n, float *out
         ifr::ItemItemParams ip;
         int rc = item_item_params(h, user_ids, n, &ip);
         if (rc) return rc;
-        if ((int64_t)ip.n_chunks * n > 0x7fffffff) return fail(h, IFR_ERR_ARG, "ifr_score_dense: batch too large");
+        if (n > (int64_t)1 << 24) return fail(h, IFR_ERR_ARG, "ifr_score_dense: more than 2^24 users in one call");
         ip.out = out; ip.ld = ld;
         if (ifr::launch_item_item(ip, h->mode == MODE_ITEM_CSR, false, (hipStream_t)stream))
             return fail(h, IFR_ERR_HIP, "ifr_score_dense: item-item launch failed");
@@ -681,7 +681,7 @@ int ifr_score_dense(ifr_handle h, const int32_t *user_ids, int64_t n, float *out
     pick_chunks(h, n, &chunk_tiles, &n_chunks);
     const int64_t n_ut = (n + ifr::USERS_PER_BLOCK - 1) / ifr::USERS_PER_BLOCK;
     const int64_t grid = n_ut * n_chunks;
-    if (grid > 0x7fffffff) return fail(h, IFR_ERR_ARG, "ifr_score_dense: batch too large");
+    if (grid > (int64_t)0xffffffffu / ifr::BLOCK) return fail(h, IFR_ERR_ARG, "ifr_score_dense: batch too large");
     ifr::DenseParams p;
     p.U = h->U; p.V = h->V; p.ibase = h->ibase; p.ubase = h->ubase; p.user_ids = user_ids; p.n = n;
     p.n_items = (int)h->n_items; p.n_tiles = h->n_tiles; p.chunk_tiles = chunk_tiles; p.n_chunks = n_chunks;

@@ -59,8 +59,8 @@ __global__ __launch_bounds__(II_BLOCK, 3) void item_item_kernel(ItemItemParams p
     unsigned long long *acc64 = reinterpret_cast<unsigned long long *>(buf);
 
     const int tid = threadIdx.x;
-    const int chunk = blockIdx.x / (unsigned)p.n;
-    const int64_t i = blockIdx.x - (int64_t)chunk * p.n;
+    const int chunk = blockIdx.y;                        // x = user: co-resident workgroups share an item chunk
+    const int64_t i = blockIdx.x;
     const int u = p.user_ids[i];
     const int c0 = chunk * CHUNK;
 
@@ -259,9 +259,9 @@ __global__ __launch_bounds__(II_BLOCK, 3) void item_item_kernel(ItemItemParams p
 
 int launch_item_item(const ItemItemParams &p, bool sparse, bool topk, hipStream_t stream)
 {
-    const int64_t grid = (int64_t)p.n_chunks * p.n;
-    if (grid <= 0 || grid > 0x7fffffff) return -1;
-    const dim3 g((unsigned)grid), b(II_BLOCK);
+    // HIP limits grid.x * block.x to 32 bits and grid.y to 65535
+    if (p.n <= 0 || p.n_chunks <= 0 || p.n > (int64_t)0xffffffffu / II_BLOCK || p.n_chunks > 65535) return -1;
+    const dim3 g((unsigned)p.n, (unsigned)p.n_chunks), b(II_BLOCK);
     if (sparse) {
         if (topk) hipLaunchKernelGGL((item_item_kernel<II_SPARSE_PASSES, true, true>), g, b, 0, stream, p);
         else hipLaunchKernelGGL((item_item_kernel<II_SPARSE_PASSES, true, false>), g, b, 0, stream, p);

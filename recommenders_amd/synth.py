@@ -64,3 +64,68 @@ def make(name, n_users=None, n_items=None, seed=None):
     tr_ptr, tr_idx, te_ptr, te_idx = interactions(rng, nu, ni, mean)
     return dict(name=name, n_users=nu, n_items=ni, k=k, U=U, V=V, ubase=ubase, ibase=ibase,
                 excl_ptr=tr_ptr, excl_idx=tr_idx, truth_ptr=te_ptr, truth_idx=te_idx)
+
+
+# ---------------------------------------------------------------------------- item-item workloads
+ITEM_CONFIGS = {
+    # name: (n_users, n_items, mean history length, seed, neighbours per row of a sparse W or None)
+    "c4_ease_mind": (262144, 50000, 30, 4, None),        # EASE, dense B 50K x 50K (10 GB fp32), MIND-large shape
+    "c5_rp3_ebnerd": (1048576, 125000, 35, 5, 256),      # RP3-beta, sparse W, EB-NeRD shape
+}
+
+
+def ease_like_matrix(n_items, seed, device=None):
+    """B = max(0, N(0, 1e-3)) with a zero diagonal (mirrors posB and the zeroed diagonal of
+    recom_ease.py:86-92).  On `device` (a torch device) the matrix is generated there in row
+    blocks; otherwise with NumPy."""
+    if device is None:
+        rng = np.random.default_rng(seed)
+        B = np.maximum(0, rng.normal(0, 1e-3, (n_items, n_items))).astype(np.float32)
+        np.fill_diagonal(B, 0.0)
+        return B
+    import torch
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    B = torch.empty((n_items, n_items), dtype=torch.float32, device=device)
+    step = 4096
+    for r in range(0, n_items, step):
+        blk = B[r:r + step]
+        blk.normal_(0, 1e-3, generator=g)
+        blk.clamp_(min=0)
+    B.fill_diagonal_(0.0)
+    return B
+
+
+def sparse_item_matrix(rng, n_items, row_nnz):
+    """CSR W with `row_nnz` strictly ascending, stratified-random columns per row and positive
+    weights of the size RP3-beta's P_iu.P_ui has (~1/degree^2)."""
+    base = (np.arange(row_nnz + 1, dtype=np.int64) * n_items) // row_nnz       # stratum k = [base[k], base[k+1])
+    width = np.diff(base)
+    cols = (base[None, :-1] + np.floor(rng.random((n_items, row_nnz)) * width[None, :]).astype(np.int64)).astype(np.int32)
+    vals = (rng.random((n_items, row_nnz)) * 1e-3).astype(np.float32)
+    ptr = np.arange(n_items + 1, dtype=np.int64) * row_nnz
+    return ptr, cols.ravel(), vals.ravel()
+
+
+def make_item(name, n_users=None, n_items=None, seed=None, device=None, row_nnz=None):
+    """Item-item workload dict: histories (train rows with weights), exclusions (= the train items),
+    truth (held-out items), and M either dense ("M") or CSR ("m_ptr", "m_idx", "m_val") + col_scale."""
+    nu, ni, mean, sd, nnz = ITEM_CONFIGS[name]
+    nu = nu if n_users is None else n_users
+    ni = ni if n_items is None else n_items
+    nnz = nnz if row_nnz is None else row_nnz
+    rng = np.random.default_rng(sd if seed is None else seed)
+    tr_ptr, tr_idx, te_ptr, te_idx = interactions(rng, nu, ni, mean, lo=5, hi=400)
+    out = dict(name=name, n_users=nu, n_items=ni, h_ptr=tr_ptr, h_idx=tr_idx, excl_ptr=tr_ptr, excl_idx=tr_idx,
+               truth_ptr=te_ptr, truth_idx=te_idx, M=None, m_ptr=None, col_scale=None)
+    cnt = np.diff(tr_ptr)
+    if nnz is None:                                  # EASE: x_uj = the rating (1.0: implicit clicks)
+        out["h_val"] = np.ones(len(tr_idx), np.float32)
+        out["M"] = ease_like_matrix(ni, sd if seed is None else seed, device)
+    else:                                            # RP3-beta: x_uj = 1/deg(u), col_scale = deg(item)^-0.7
+        out["h_val"] = np.repeat((1.0 / np.maximum(cnt, 1)).astype(np.float32), cnt)
+        out["m_ptr"], out["m_idx"], out["m_val"] = sparse_item_matrix(rng, ni, min(nnz, ni))
+        deg = np.bincount(tr_idx, minlength=ni).astype(np.float64)
+        with np.errstate(divide="ignore"):
+            out["col_scale"] = (1.0 / np.maximum(deg, 1.0) ** 0.7).astype(np.float32)
+    return out

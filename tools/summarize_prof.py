@@ -1,0 +1,38 @@
+"""Summarise the rocprofv3 output of tools/prof.sh: per-launch counter means of one kernel and the
+HBM traffic corrected as /opt/skills/guides/MI355X_MICROARCH.md prescribes for gfx950
+(FETCH_SIZE / WRITE_SIZE are in KiB; FETCH_SIZE counts 128-B requests at 64 B: double it)."""
+import csv, glob, json, re, sys
+
+def main():
+    out_dir, kregex, args = sys.argv[1], sys.argv[2], sys.argv[3]
+    rx = re.compile(kregex)
+    res = {"command": f"rocprofv3 --pmc <group> --kernel-trace -- python3 bench.py --no-cpu {args} (one run per counter group, tools/prof.sh)",
+           "kernel_regex": kregex, "counters": {}}
+    for f in glob.glob(f"{out_dir}/pmc_*/*/*_counter_collection.csv"):
+        acc = {}
+        for row in csv.DictReader(open(f)):
+            if rx.search(row["Kernel_Name"]):
+                acc.setdefault(row["Counter_Name"], {}).setdefault(row["Dispatch_Id"], 0.0)
+                acc[row["Counter_Name"]][row["Dispatch_Id"]] += float(row["Counter_Value"])
+                res["kernel"] = row["Kernel_Name"]
+        for name, per in acc.items():
+            v = list(per.values())
+            res["counters"][name] = {"launches": len(v), "mean_per_launch": sum(v) / len(v)}
+    for f in glob.glob(f"{out_dir}/trace/*/*_kernel_stats.csv"):
+        for row in csv.DictReader(open(f)):
+            if rx.search(row["Name"]):
+                res["kernel_trace"] = {"calls": int(row["Calls"]), "average_ns": float(row["AverageNs"]),
+                                       "min_ns": float(row["MinNs"]), "max_ns": float(row["MaxNs"])}
+    c = res["counters"]
+    if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+        fr, wr = c["FETCH_SIZE"]["mean_per_launch"] * 1024, c["WRITE_SIZE"]["mean_per_launch"] * 1024
+        res["hbm_traffic_per_launch_bytes"] = {"fetch_raw": fr, "fetch_corrected_x2": 2 * fr, "write": wr,
+                                               "total_corrected": 2 * fr + wr}
+        if "kernel_trace" in res:
+            res["hbm_gbps_corrected"] = (2 * fr + wr) / res["kernel_trace"]["average_ns"]
+    if "SQ_VALU_MFMA_BUSY_CYCLES" in c and "SQ_BUSY_CYCLES" in c:
+        # MFMA busy is summed over the 4 SIMDs of every CU, SQ_BUSY_CYCLES over shader engines x XCDs
+        res["mfma_busy_per_wave_cycle"] = c["SQ_VALU_MFMA_BUSY_CYCLES"]["mean_per_launch"] / max(c["SQ_WAVE_CYCLES"]["mean_per_launch"], 1)
+    print(json.dumps(res, indent=1))
+
+main()
