@@ -64,13 +64,13 @@ def cpu_baseline_item(w, n_sample, shift):
 
 
 def item_algorithmic_bytes(w):
-    """dense M: 4*I bytes per history entry; CSR M: 8 bytes per nonzero of every
-    history row plus the 4*I-byte score vector per user."""
+    """dense M: 4*I bytes per history entry; CSR M: 8 bytes (index + value) per
+    nonzero of every history row (the score vector stays in LDS, so its 4*I bytes do not count)."""
     n, I = w["n_users"], w["n_items"]
     if w["M"] is not None:
         return 4.0 * I * float(w["h_ptr"][n])
     row_nnz = np.diff(w["m_ptr"])
-    return 8.0 * float(row_nnz[w["h_idx"][: w["h_ptr"][n]]].sum()) + 4.0 * I * n
+    return 8.0 * float(row_nnz[w["h_idx"][: w["h_ptr"][n]]].sum())
 
 
 def cpu_strong(w, n_sample):
@@ -89,11 +89,18 @@ def cpu_strong(w, n_sample):
     return dict(value=done / dt, unit="users/s", kind="numpy sgemm+argpartition", sample=f"{done} users, {dt:.1f} s")
 
 
+PROFILED = {"c2_wmf_ml20m": ("r01_c2_pmc.json", 138493, 26744), "c4_ease_mind": ("r01_c4_pmc.json", 262144, 50000),
+            "c5_rp3_ebnerd": ("r01_c5_pmc.json", 1048576, 125000)}
+
+
 def measured_traffic(config, n_users, n_items):
-    """HBM bytes per launch of the fused kernel from the committed rocprofv3 PMC passes of this same
-    command (profiles/*_pmc.json, made by tools/prof_c2.sh); None when the workload differs."""
-    path = os.path.join(ROOT, "profiles", "r01_c2_pmc.json")
-    if config != "c2_wmf_ml20m" or (n_users, n_items) != (138493, 26744) or not os.path.exists(path):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same
+    command (profiles/*_pmc.json, made by tools/prof.sh); None when the workload differs."""
+    if config not in PROFILED:
+        return None
+    name, nu, ni = PROFILED[config]
+    path = os.path.join(ROOT, "profiles", name)
+    if (n_users, n_items) != (nu, ni) or not os.path.exists(path):
         return None
     with open(path) as f:
         return json.load(f)["hbm_traffic_per_launch_bytes"]["total_corrected"]
@@ -194,8 +201,8 @@ def main():
                         + ("" if dense else f", {int(np.diff(w['m_ptr']).mean())} neighbours/row")
                         + f", top-{TOPK} + NDCG@{TOPK}/Recall@{TOPK}/Precision@{TOPK}")
             roof = {"bound": "hbm", "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                    "frac": achieved / PEAK_HBM_GBS, "traffic": None,
-                    "kernel": "item_item_kernel", "avg_launch_ms": avg_ms, "launches": launches,
+                    "frac": achieved / PEAK_HBM_GBS, "traffic": measured_traffic(args.config, n, w["n_items"]),
+                    "kernel": "item_item_kernel" if dense else "item_sparse_topk_kernel", "avg_launch_ms": avg_ms, "launches": launches,
                     "bytes_per_launch": bytes_per_launch}
             cfg = {"workload": workload, "users_per_gpu": n, "items": w["n_items"], "topk": TOPK,
                    "parallelism": f"users sharded x{world}, item matrix replicated"}

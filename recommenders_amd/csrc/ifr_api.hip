@@ -473,7 +473,7 @@ static int item_item_params(ifr_handle h, const int32_t *user_ids, int64_t n, if
     if (!h->hs_ptr) return fail(h, IFR_ERR_STATE, "item-item model: histories not set (ifr_set_history_csr)");
     memset(p, 0, sizeof(*p));
     p->M = h->iiM; p->ldm = h->ii_ld;
-    p->cptr = h->ii_cptr; p->m_idx = h->ii_idx; p->m_val = h->ii_val;
+    p->cptr = h->ii_cptr; p->m_idx = h->ii_idx; p->m_val = h->ii_val; p->m_nnz = h->ii_nnz;
     p->fx_shift = h->mode == MODE_ITEM_CSR ? fixed_point_shift(h) : 0;
     p->pen = h->ii_pen;
     p->h_ptr = h->hs_ptr; p->h_idx = h->hs_idx; p->h_val = h->hs_val; p->h_rows = h->hs_rows;
@@ -507,16 +507,22 @@ static int rank_topk_item_item(ifr_handle h, const int32_t *user_ids, int64_t n,
     int rc = item_item_params(h, user_ids, n, &p);
     if (rc) return rc;
     if (n > (int64_t)1 << 24) return fail(h, IFR_ERR_ARG, "ifr_rank_topk: more than 2^24 users in one call, split the user list");
+    p.K = K; p.KL = KL;
+    std::pair<hipEvent_t, hipEvent_t> ev;
+    if (h->mode == MODE_ITEM_CSR) {                  // one workgroup per user, final lists written directly
+        rc = prof_begin(h, s, &ev);
+        if (rc) return rc;
+        if (ifr::launch_item_sparse_topk(p, out_ids, out_scores, s)) return fail(h, IFR_ERR_HIP, "ifr_rank_topk: item-item launch failed");
+        return prof_end(h, s, ev, (double)n * (double)h->n_items);
+    }
     const size_t entries = (size_t)n * p.n_chunks * KL;
     rc = grow(h, &h->ws_part, &h->ws_part_bytes, entries * 8);
     if (rc) return rc;
-    p.K = K; p.KL = KL;
     p.part_scores = (float *)h->ws_part;
     p.part_ids = (int32_t *)((char *)h->ws_part + entries * 4);
-    std::pair<hipEvent_t, hipEvent_t> ev;
     rc = prof_begin(h, s, &ev);
     if (rc) return rc;
-    if (ifr::launch_item_item(p, h->mode == MODE_ITEM_CSR, true, s)) return fail(h, IFR_ERR_HIP, "ifr_rank_topk: item-item launch failed");
+    if (ifr::launch_item_item(p, false, true, s)) return fail(h, IFR_ERR_HIP, "ifr_rank_topk: item-item launch failed");
     rc = prof_end(h, s, ev, (double)n * (double)h->n_items);
     if (rc) return rc;
     const size_t smem = (size_t)p.n_chunks * KL * 8;

@@ -11,6 +11,7 @@ struct ItemItemParams {
     const int64_t *cptr;         // sparse: [n_items][n_chunks + 1] entry positions per item chunk
     const int32_t *m_idx;        //         column of every entry
     const float *m_val;
+    int64_t m_nnz;               //         entries in m_idx / m_val
     int fx_shift;                //         fixed-point scale 2^fx_shift
     const float *pen;            // [>= n_chunks * chunk] column scale or null
     const int64_t *h_ptr;        // history CSR
@@ -32,6 +33,7 @@ struct ItemItemParams {
 };
 
 int launch_item_item(const ItemItemParams &p, bool sparse, bool topk, hipStream_t stream);
+int launch_item_sparse_topk(const ItemItemParams &p, int32_t *out_ids, float *out_scores, hipStream_t stream);
 int item_item_chunk(bool sparse);
 int item_item_pass();
 int launch_validate_csr(const int64_t *ptr, const int32_t *idx, int64_t n_rows, int n_cols, int need_sorted, int *bad,

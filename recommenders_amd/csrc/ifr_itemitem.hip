@@ -257,14 +257,278 @@ __global__ __launch_bounds__(II_BLOCK, 3) void item_item_kernel(ItemItemParams p
     }
 }
 
+// ------------------------------------------------------------------------------------
+// CSR M, top-K: one workgroup per user sweeps the item chunks with ONE running top-K list.
+// Per chunk the work is proportional to the nonzeros that fall into it, not to the chunk:
+//   accumulate : 16-lane groups walk the chunk's segment of each history row; 64-bit fixed-point
+//                LDS atomics as above; the first touch of a column (atomicOr on a bitmap) appends
+//                it to a touched list;
+//   drain      : only touched columns are converted, scaled, tested against the current K-th
+//                best key and, if they pass, looked up in the exclusion row (LDS copy, binary
+//                search); their accumulators are reset on the way, so the 32 KB are zeroed once;
+//   merge      : qualifiers and the current list are ranked by counting (keys are unique:
+//                (orderable score, ~item) packed in 64 bits, larger = better);
+//   zeros      : untouched columns score exactly 0 * col_scale.  They can only matter while the
+//                list is not full or its K-th key is not above the chunk's best possible zero,
+//                and then only the K lowest item ids among them: a block prefix count picks those.
+// The end of a row's chunk segment is the start of its next one, so each (history row, chunk)
+// costs one pointer load, issued one chunk ahead.
+// ------------------------------------------------------------------------------------
+constexpr int SP_CHUNK = II_SPARSE_PASSES * II_PASS;   // 4096 columns, 32 KB of accumulators
+constexpr int SP_HIST = 256;                            // history rows staged per round
+constexpr int SP_SLAB = II_BLOCK;                       // touched columns drained per merge
+constexpr int SP_EXCAP = 512;                           // exclusion row entries kept in LDS
+
+__device__ __forceinline__ uint32_t sp_float_key(float x)
+{
+    const uint32_t b = __float_as_uint(x);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float sp_key_float(uint32_t k)
+{
+    return __uint_as_float((k & 0x80000000u) ? (k ^ 0x80000000u) : ~k);
+}
+__device__ __forceinline__ unsigned long long sp_key(float s, int col)
+{
+    return ((unsigned long long)sp_float_key(s) << 32) | (uint32_t)(~col);
+}
+
+__global__ __launch_bounds__(II_BLOCK, 3) void item_sparse_topk_kernel(ItemItemParams p, int32_t *out_ids,
+                                                                       float *out_scores)
+{
+    __shared__ unsigned long long acc64[SP_CHUNK];
+    __shared__ uint32_t tbm[SP_CHUNK / 32];
+    __shared__ uint16_t tlist[SP_CHUNK];
+    __shared__ int hj[SP_HIST];
+    __shared__ float hx[SP_HIST];
+    __shared__ int64_t s0[SP_HIST], s1[SP_HIST];        // current chunk's segment of each staged row
+    __shared__ int exl[SP_EXCAP];
+    __shared__ unsigned long long qkey[SP_SLAB + 32];
+    __shared__ unsigned long long top[32];
+    __shared__ int s_ntouch, s_nq, s_cnt;
+    __shared__ int wsum[II_BLOCK / 64];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int g = tid / II_GROUP, l = tid % II_GROUP;
+    const int64_t i = blockIdx.x;
+    const int u = p.user_ids[i];
+    const int K = p.K;
+    const int nc1 = p.n_chunks + 1;
+
+    int64_t hb = 0, he = 0, eb = 0, ee = 0;
+    if (u >= 0 && u < p.h_rows) { hb = p.h_ptr[u]; he = p.h_ptr[u + 1]; }
+    if (p.ex_ptr != nullptr && u >= 0 && u < p.ex_rows) { eb = p.ex_ptr[u]; ee = p.ex_ptr[u + 1]; }
+    const int n_ex = (int)(ee - eb);
+    const bool ex_lds = n_ex <= SP_EXCAP;
+    const bool single = (he - hb) <= SP_HIST;           // the whole history fits one staging round
+
+    for (int w = tid; w < SP_CHUNK; w += II_BLOCK) acc64[w] = 0ull;
+    for (int w = tid; w < SP_CHUNK / 32; w += II_BLOCK) tbm[w] = 0u;
+    if (ex_lds) for (int w = tid; w < n_ex; w += II_BLOCK) exl[w] = p.ex_idx[eb + w];
+    if (tid < 32) top[tid] = 0ull;
+    if (tid == 0) { s_ntouch = 0; s_nq = 0; s_cnt = 0; }
+    if (single) {
+        const int m = (int)(he - hb);
+        for (int e = tid; e < m; e += II_BLOCK) {
+            const int j = p.h_idx[hb + e];
+            hj[e] = j;
+            hx[e] = p.h_val[hb + e];
+            const int64_t *cp = p.cptr + (int64_t)j * nc1;
+            s0[e] = cp[0];
+            s1[e] = cp[1];
+        }
+    }
+    __syncthreads();
+
+    auto excluded = [&](int col) -> bool {
+        int lo = 0, hi = n_ex;
+        if (ex_lds) {
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (exl[mid] < col) lo = mid + 1; else hi = mid; }
+            return lo < n_ex && exl[lo] == col;
+        }
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (p.ex_idx[eb + mid] < col) lo = mid + 1; else hi = mid; }
+        return lo < n_ex && p.ex_idx[eb + lo] == col;
+    };
+    // qualifiers in qkey[0, s_nq) + the current list -> the new list (block-uniform control flow)
+    auto merge = [&]() {
+        const int nq = s_nq;
+        if (nq == 0) return;
+        const int cnt = s_cnt;
+        if (tid < cnt) qkey[nq + tid] = top[tid];
+        __syncthreads();
+        const int total = nq + cnt;
+        for (int e = tid; e < total; e += II_BLOCK) {
+            const unsigned long long k = qkey[e];
+            int rank = 0;
+            for (int x = 0; x < total; ++x) rank += qkey[x] > k ? 1 : 0;
+            if (rank < K) top[rank] = k;
+        }
+        __syncthreads();
+        if (tid == 0) { s_cnt = min(K, total); s_nq = 0; }
+        __syncthreads();
+    };
+
+    // In single mode the first 16 entries of the NEXT chunk's segment of up to two rows per lane
+    // group are loaded one chunk ahead (pf_*), so a typical user (<= 32 history rows, segments of
+    // <= 16 entries) never waits on HBM inside the chunk loop.  A prefetch may read past its
+    // segment (never past the array); such entries are dropped by the q < q1 test at use.
+    int pf_i[2] = {0, 0};
+    float pf_v[2] = {0.f, 0.f};
+    const int m1 = single ? (int)(he - hb) : 0;
+    auto prefetch = [&](int (&ri)[2], float (&rv)[2], const int64_t *start) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int e = g + t * (II_BLOCK / II_GROUP);
+            if (e < m1) {
+                const int64_t q = start[e] + l;
+                if (q < p.m_nnz) { ri[t] = p.m_idx[q]; rv[t] = p.m_val[q]; }
+            }
+        }
+    };
+    if (single) prefetch(pf_i, pf_v, s0);
+
+    for (int chunk = 0; chunk < p.n_chunks; ++chunk) {
+        const int c0 = chunk * SP_CHUNK;
+        auto apply = [&](int ci, float wv, double x) {
+            const int c = ci - c0;
+            const double pr = x * (double)wv;                                  // exact: 24 x 24 bits
+            const long long v = __double2ll_rn(ldexp(pr, p.fx_shift));          // nearest even
+            atomicAdd(&acc64[c], (unsigned long long)v);
+            const uint32_t bit = 1u << (c & 31);
+            if (!(atomicOr(&tbm[c >> 5], bit) & bit)) tlist[atomicAdd(&s_ntouch, 1)] = (uint16_t)c;
+        };
+        // ---- accumulate
+        if (single) {
+            const int m = m1;
+            int nf_i[2] = {0, 0};
+            float nf_v[2] = {0.f, 0.f};
+            int64_t nxt = 0;
+            if (chunk + 1 < p.n_chunks) {
+                prefetch(nf_i, nf_v, s1);
+                // the boundary after the NEXT chunk, in flight while this chunk is accumulated
+                if (tid < m) nxt = p.cptr[(int64_t)hj[tid] * nc1 + chunk + 2];
+            }
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int e = g + t * (II_BLOCK / II_GROUP);
+                if (e < m) {
+                    const double x = (double)hx[e];
+                    const int64_t q1 = s1[e];
+                    int64_t q = s0[e] + l;
+                    if (q < q1) apply(pf_i[t], pf_v[t], x);
+                    for (q += II_GROUP; q < q1; q += II_GROUP) apply(p.m_idx[q], p.m_val[q], x);
+                }
+            }
+            for (int e = g + 2 * (II_BLOCK / II_GROUP); e < m; e += II_BLOCK / II_GROUP) {
+                const double x = (double)hx[e];
+                const int64_t q1 = s1[e];
+                for (int64_t q = s0[e] + l; q < q1; q += II_GROUP) apply(p.m_idx[q], p.m_val[q], x);
+            }
+            __syncthreads();
+            if (tid < m) { s0[tid] = s1[tid]; s1[tid] = nxt; }
+            pf_i[0] = nf_i[0]; pf_i[1] = nf_i[1]; pf_v[0] = nf_v[0]; pf_v[1] = nf_v[1];
+        } else {
+            for (int64_t base = hb; base < he; base += SP_HIST) {
+                const int m = (int)min((int64_t)SP_HIST, he - base);
+                __syncthreads();
+                for (int e = tid; e < m; e += II_BLOCK) {
+                    const int j = p.h_idx[base + e];
+                    hj[e] = j;
+                    hx[e] = p.h_val[base + e];
+                    const int64_t *cp = p.cptr + (int64_t)j * nc1 + chunk;
+                    s0[e] = cp[0];
+                    s1[e] = cp[1];
+                }
+                __syncthreads();
+                for (int e = g; e < m; e += II_BLOCK / II_GROUP) {
+                    const double x = (double)hx[e];
+                    const int64_t q1 = s1[e];
+                    for (int64_t q = s0[e] + l; q < q1; q += II_GROUP) apply(p.m_idx[q], p.m_val[q], x);
+                }
+            }
+        }
+        __syncthreads();
+        // ---- drain the touched columns, one slab per merge
+        const int nt = s_ntouch;
+        for (int sbase = 0; sbase < nt; sbase += SP_SLAB) {
+            const int cnt = s_cnt;
+            const unsigned long long tau = cnt == K ? top[K - 1] : 0ull;
+            const int e = sbase + tid;
+            if (e < nt) {
+                const int lc = tlist[e];
+                const long long a = (long long)acc64[lc];
+                acc64[lc] = 0ull;
+                const int col = c0 + lc;
+                float s = (float)ldexp((double)a, -p.fx_shift);
+                if (p.pen != nullptr) s *= p.pen[col];
+                if (s == s) {
+                    if (s == 0.0f) s = 0.0f;                                   // -0 ranks as +0
+                    const unsigned long long k = sp_key(s, col);
+                    if (k > tau && !excluded(col)) qkey[atomicAdd(&s_nq, 1)] = k;
+                }
+            }
+            __syncthreads();
+            merge();
+        }
+        // ---- untouched columns (score 0 * col_scale), only while they can still enter the list
+        {
+            const int cnt = s_cnt;
+            const unsigned long long tau = cnt == K ? top[K - 1] : 0ull;
+            if (cnt < K || sp_key(0.0f, c0) > tau) {
+                int mine = 0;
+                uint32_t okbits = 0;
+#pragma unroll 4
+                for (int v = 0; v < 16; ++v) {
+                    const int lc = 16 * tid + v;
+                    const int col = c0 + lc;
+                    bool ok = col < p.n_items && !((tbm[lc >> 5] >> (lc & 31)) & 1u);
+                    if (ok && p.pen != nullptr) { const float z = 0.0f * p.pen[col]; ok = z == z; }
+                    if (ok) ok = sp_key(0.0f, col) > tau && !excluded(col);
+                    if (ok) { okbits |= 1u << v; ++mine; }
+                }
+                int incl = mine;                                              // block exclusive prefix of `mine`
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(incl, off); if (lane >= off) incl += t; }
+                if (lane == 63) wsum[wave] = incl;
+                __syncthreads();
+                int before = incl - mine;
+                for (int w = 0; w < wave; ++w) before += wsum[w];
+                for (int v = 0; v < 16 && before < K; ++v)
+                    if (okbits & (1u << v)) { qkey[atomicAdd(&s_nq, 1)] = sp_key(0.0f, c0 + 16 * tid + v); ++before; }
+                __syncthreads();
+                merge();
+            }
+        }
+        // ---- reset the touched bitmap and list for the next chunk
+        for (int w = tid; w < SP_CHUNK / 32; w += II_BLOCK) tbm[w] = 0u;
+        if (tid == 0) s_ntouch = 0;
+        __syncthreads();
+    }
+
+    const int cnt = s_cnt;
+    if (tid < K) {
+        const unsigned long long k = top[tid];
+        out_ids[i * K + tid] = tid < cnt ? (int32_t)(~(uint32_t)k) : -1;
+        out_scores[i * K + tid] = tid < cnt ? sp_key_float((uint32_t)(k >> 32)) : -INFINITY;
+    }
+}
+
+int launch_item_sparse_topk(const ItemItemParams &p, int32_t *out_ids, float *out_scores, hipStream_t stream)
+{
+    if (p.n <= 0 || p.n > (int64_t)0xffffffffu / II_BLOCK || p.K < 1 || p.K > 32) return -1;
+    hipLaunchKernelGGL(item_sparse_topk_kernel, dim3((unsigned)p.n), dim3(II_BLOCK), 0, stream, p, out_ids, out_scores);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
 int launch_item_item(const ItemItemParams &p, bool sparse, bool topk, hipStream_t stream)
 {
     // HIP limits grid.x * block.x to 32 bits and grid.y to 65535
     if (p.n <= 0 || p.n_chunks <= 0 || p.n > (int64_t)0xffffffffu / II_BLOCK || p.n_chunks > 65535) return -1;
     const dim3 g((unsigned)p.n, (unsigned)p.n_chunks), b(II_BLOCK);
     if (sparse) {
-        if (topk) hipLaunchKernelGGL((item_item_kernel<II_SPARSE_PASSES, true, true>), g, b, 0, stream, p);
-        else hipLaunchKernelGGL((item_item_kernel<II_SPARSE_PASSES, true, false>), g, b, 0, stream, p);
+        if (topk) return -1;                             // CSR top-K is item_sparse_topk_kernel
+        hipLaunchKernelGGL((item_item_kernel<II_SPARSE_PASSES, true, false>), g, b, 0, stream, p);
     } else {
         if (topk) hipLaunchKernelGGL((item_item_kernel<II_DENSE_PASSES, false, true>), g, b, 0, stream, p);
         else hipLaunchKernelGGL((item_item_kernel<II_DENSE_PASSES, false, false>), g, b, 0, stream, p);
