@@ -37,7 +37,7 @@ enum {
     IFR_ERR_NOMEM = -4       /* device allocation failed                           */
 };
 
-#define IFR_MAX_FACTORS 128  /* latent dimension k supported by the fused kernel   */
+#define IFR_MAX_FACTORS 256  /* latent dimension k supported by the fused kernel   */
 #define IFR_MAX_TOPK 32      /* K supported by the fused score+select kernel       */
 
 /* Library / handle life cycle.  (No reference counterpart: the reference keeps model

@@ -106,7 +106,7 @@ int grow(ifr_handle h, void **p, size_t *have, size_t need)
     return IFR_OK;
 }
 
-int pad_k(int k) { return k <= 32 ? 32 : (k <= 64 ? 64 : 128); }
+int pad_k(int k) { return k <= 32 ? 32 : (k <= 64 ? 64 : (k <= 128 ? 128 : 256)); }
 
 void pick_chunks(ifr_handle h, int64_t n, int *chunk_tiles, int *n_chunks)
 {
@@ -130,7 +130,8 @@ void launch_topk_kd(int KD, bool has_base, const ifr::TopkParams &p, int grid, h
 {
     if (KD == 32) launch_topk<32, KL>(has_base, p, grid, s);
     else if (KD == 64) launch_topk<64, KL>(has_base, p, grid, s);
-    else launch_topk<128, KL>(has_base, p, grid, s);
+    else if (KD == 128) launch_topk<128, KL>(has_base, p, grid, s);
+    else launch_topk<256, KL>(has_base, p, grid, s);
 }
 
 template <int KD>
@@ -253,7 +254,7 @@ int ifr_set_factors(ifr_handle h, const float *U, int64_t n_users, const float *
 {
     if (!h) return IFR_ERR_ARG;
     if (!U || !V || n_users <= 0 || n_items <= 0 || k <= 0) return fail(h, IFR_ERR_ARG, "ifr_set_factors: null/empty input");
-    if (k > IFR_MAX_FACTORS) return fail(h, IFR_ERR_ARG, "ifr_set_factors: k > IFR_MAX_FACTORS (128)");
+    if (k > IFR_MAX_FACTORS) return fail(h, IFR_ERR_ARG, "ifr_set_factors: k > IFR_MAX_FACTORS (256)");
     if (n_items > (int64_t)1 << 30) return fail(h, IFR_ERR_ARG, "ifr_set_factors: n_items too large");
     IFR_HIP(h, hipSetDevice(h->device));
     dfree(h->U); dfree(h->V); dfree(h->ibase); dfree(h->ubase);
@@ -695,7 +696,8 @@ int ifr_score_dense(ifr_handle h, const int32_t *user_ids, int64_t n, float *out
     hipStream_t s = (hipStream_t)stream;
     if (h->KD == 32) launch_dense<32>(h->has_base, p, (int)grid, s);
     else if (h->KD == 64) launch_dense<64>(h->has_base, p, (int)grid, s);
-    else launch_dense<128>(h->has_base, p, (int)grid, s);
+    else if (h->KD == 128) launch_dense<128>(h->has_base, p, (int)grid, s);
+    else launch_dense<256>(h->has_base, p, (int)grid, s);
     IFR_HIP(h, hipGetLastError());
     return IFR_OK;
 }

@@ -109,7 +109,7 @@ __device__ __forceinline__ float list_tau(const float (&ls)[KL], int K)
 // stream the same item chunk through L2.
 // ------------------------------------------------------------------------------------
 template <int KD, int KL, bool HAS_BASE>
-__global__ __launch_bounds__(BLOCK, 2) void score_topk_kernel(TopkParams p)
+__global__ __launch_bounds__(BLOCK, KD > 128 ? 1 : 2) void score_topk_kernel(TopkParams p)
 {
     constexpr int ROW = KD + 4;                 // padded LDS row (floats); +4 => conflict-free b128 reads
     constexpr int C4 = KD / 4;                  // float4 chunks per factor row
@@ -228,7 +228,8 @@ __global__ __launch_bounds__(BLOCK, 2) void score_topk_kernel(TopkParams p)
         // never compares '>', and a running max per 4-register group.  sched_barrier(0) keeps the
         // steps apart so this VALU work issues while the step's last MFMA is still in the pipe.
         constexpr int G = KD / 8;               // k-groups per tile
-        constexpr int RPG = 16 / G;             // score registers selected per k-group
+        constexpr int SEL_G = G < 16 ? G : 16;  // k-groups that carry select work (KD = 256: the first 16)
+        constexpr int RPG = 16 / SEL_G;         // score registers selected per such k-group
         f32x16 accN = {0};
         float ibN[16];
         const float *arow = &vt[buf][j][4 * h];
@@ -250,7 +251,7 @@ __global__ __launch_bounds__(BLOCK, 2) void score_topk_kernel(TopkParams p)
             accN = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[2], ureg[g][2], accN, 0, 0, 0);
             accN = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[3], ureg[g][3], accN, 0, 0, 0);
 #pragma unroll
-            for (int r = g * RPG; r < (g + 1) * RPG; ++r) {
+            for (int r = g * RPG; r < (g < SEL_G ? (g + 1) * RPG : 0); ++r) {
                 const int bit = (r & 3) + 8 * (r >> 2);
                 float sc = HAS_BASE ? ((ibC[r] + ub) + accC[r]) : accC[r];      // (ibase + ubase) + dot
                 const uint32_t kill = (uint32_t)(-(int32_t)((mm >> bit) & 1u)); // 0 or ~0

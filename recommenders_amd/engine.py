@@ -257,7 +257,7 @@ class HipScorer:
 
     # ------------------------------------------------------------------ introspection
     def chain_order(self):
-        perm = (ctypes.c_int32 * 128)()
+        perm = (ctypes.c_int32 * 256)()
         n = ctypes.c_int(0)
         self._check(self._lib.ifr_factor_chain_order(self._h, perm, ctypes.byref(n)))
         return np.asarray(perm[: n.value], dtype=np.int32)

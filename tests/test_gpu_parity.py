@@ -46,7 +46,8 @@ def _oracle(w, users, ks, kmax, kperm, want_auc=False):
                                      w["truth_ptr"], w["truth_idx"], ks, want_auc, kmax, kperm=kp, n_threads=8)
 
 
-@pytest.mark.parametrize("k,bias,K", [(128, False, 10), (50, True, 10), (10, True, 5), (128, True, 20), (64, False, 32)])
+@pytest.mark.parametrize("k,bias,K", [(128, False, 10), (50, True, 10), (10, True, 5), (128, True, 20), (64, False, 32),
+                                      (200, False, 10), (256, True, 20)])   # 200 = the reference's WMF default k
 def test_topk_bit_exact_vs_oracle(torch, k, bias, K):
     w = _workload(1000 + k + K, 777, 3001, k, bias)
     sc = _scorer(w)
@@ -154,8 +155,9 @@ def test_metrics_vs_oracle(torch):
             assert per_user[u, 6 * q + 5] == pytest.approx(orc.ncrr(pos, ids_h[u], k), abs=1e-12)
 
 
-def test_dense_scores_match_fused_and_auc(torch):
-    w = _workload(9, 260, 1500, 50, True)
+@pytest.mark.parametrize("k", [50, 200])
+def test_dense_scores_match_fused_and_auc(torch, k):
+    w = _workload(9, 260, 1500, k, True)
     sc = _scorer(w)
     users = np.arange(w["n_users"], dtype=np.int32)
     dense = sc.score_dense(users)
