@@ -48,7 +48,8 @@ int ifr_destroy(ifr_handle h);
 const char *ifr_last_error(ifr_handle h);
 
 /* Launch tuning (no reference counterpart).  "chunks": item chunks per user tile in the fused
- * kernel (0 = heuristic); "target_blocks": workgroups the heuristic aims for. */
+ * kernel (0 = heuristic); "target_blocks": workgroups the heuristic aims for; "catalogue_items":
+ * see ifr_pad_scores_min. */
 int ifr_set_option(ifr_handle h, const char *name, int64_t value);
 
 /* Model parameters of a dot-product model: score(u,i) = (ibase[i] + ubase[u]) + <U[u], V[i]>.
@@ -160,6 +161,14 @@ int ifr_rank_full(ifr_handle h, const int32_t *user_ids, int64_t n, const float 
  * indexed by item id; items: dev [m]; out_ids: dev [m]. */
 int ifr_rank_items(ifr_handle h, const float *scores, int64_t n_scores, const int32_t *items, int64_t m,
                    int32_t *out_ids, void *stream);
+
+/* Items unknown to the model (evaluation with exclude_unknowns = False, cornac/eval_methods/
+ * base_method.py:262-279): after ifr_set_option(h, "catalogue_items", N) with N > n_items,
+ * ifr_auc_dense and ifr_rank_full treat score rows as N items wide (ld >= N, exclusions < N
+ * apply), and ifr_pad_scores_min fills columns [n_items, N) of each row with the row's minimum
+ * over the known items -- the padding of Recommender.rank (cornac/models/recommender.py:631-635).
+ * scores: dev [n][ld] whose first n_items columns were written by ifr_score_dense. */
+int ifr_pad_scores_min(ifr_handle h, float *scores, int64_t n, int64_t ld, void *stream);
 
 /* Kernel timing with HIP events on the launch stream (used by bench.py for the roofline
  * figure; no reference counterpart).  After ifr_profile_enable(h, 1) every ifr_rank_topk

@@ -39,6 +39,7 @@ SIGNATURES = {
     "ifr_score_dense": (ctypes.c_int, [vp, vp, ctypes.c_int64, vp, ctypes.c_int64, vp]),
     "ifr_auc_dense": (ctypes.c_int, [vp, vp, ctypes.c_int64, vp, ctypes.c_int64, vp, vp]),
     "ifr_rank_full": (ctypes.c_int, [vp, vp, ctypes.c_int64, vp, ctypes.c_int64, vp, vp, vp]),
+    "ifr_pad_scores_min": (ctypes.c_int, [vp, vp, ctypes.c_int64, ctypes.c_int64, vp]),
     "ifr_profile_enable": (ctypes.c_int, [vp, ctypes.c_int]),
     "ifr_profile_read": (ctypes.c_int, [vp, c_f64p, c_i64p, c_f64p]),
     "ifr_factor_chain_order": (ctypes.c_int, [vp, c_i32p, ctypes.POINTER(ctypes.c_int)]),

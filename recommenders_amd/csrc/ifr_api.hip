@@ -69,6 +69,7 @@ struct ifr_handle_s {
     int opt_target_blocks = 4096;
     int opt_share_bounds = 1;    // share per-user lower bounds between item chunks
     int opt_debug = 0;           // dev-only kernel ablation mode (see TopkParams::dbg)
+    int64_t opt_catalogue = 0;   // items the dense-row consumers rank (0 = n_items; > n_items: items unknown to the model)
     // profiling
     bool prof = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_used, ev_free;
@@ -140,6 +141,8 @@ void launch_dense(bool has_base, const ifr::DenseParams &p, int grid, hipStream_
     if (has_base) hipLaunchKernelGGL((ifr::score_dense_kernel<KD, true>), dim3(grid), dim3(ifr::BLOCK), 0, s, p);
     else hipLaunchKernelGGL((ifr::score_dense_kernel<KD, false>), dim3(grid), dim3(ifr::BLOCK), 0, s, p);
 }
+
+int64_t catalogue_items(ifr_handle h) { return h->opt_catalogue > h->n_items ? h->opt_catalogue : h->n_items; }
 
 void clear_item_model(ifr_handle h)
 {
@@ -244,6 +247,11 @@ int ifr_set_option(ifr_handle h, const char *name, int64_t value)
     if (!strcmp(name, "chunks")) h->opt_chunks = (int)value;
     else if (!strcmp(name, "share_bounds")) h->opt_share_bounds = (int)value;
     else if (!strcmp(name, "debug_mode")) h->opt_debug = (int)value;
+    else if (!strcmp(name, "catalogue_items")) {
+        if (value != 0 && (value < h->n_items || value > (int64_t)1 << 30))
+            return fail(h, IFR_ERR_ARG, "catalogue_items must be 0 or >= the model's n_items");
+        h->opt_catalogue = value;
+    }
     else if (!strcmp(name, "target_blocks")) h->opt_target_blocks = (int)std::max<int64_t>(1, value);
     else return fail(h, IFR_ERR_ARG, std::string("unknown option ") + name);
     return IFR_OK;
@@ -278,6 +286,7 @@ int ifr_set_factors(ifr_handle h, const float *U, int64_t n_users, const float *
     drop_csrs_if_catalogue_changes(h, n_items);
     h->n_users = n_users; h->n_items = n_items; h->k = k; h->KD = KD; h->n_tiles = n_tiles;
     h->mode = MODE_FACTOR;
+    h->opt_catalogue = 0;
     // CSR data set for another catalogue size would index out of range
     return IFR_OK;
 }
@@ -361,7 +370,7 @@ int ifr_set_item_matrix_dense(ifr_handle h, const float *M, int64_t n_items, int
     h->ii_chunks = (int)((n_items + chunk - 1) / chunk);
     int rc = set_col_scale(h, col_scale, n_items, (int64_t)h->ii_chunks * chunk);
     if (rc) return rc;
-    h->n_items = n_items; h->n_users = 0; h->mode = MODE_ITEM_DENSE;
+    h->n_items = n_items; h->n_users = 0; h->mode = MODE_ITEM_DENSE; h->opt_catalogue = 0;
     return IFR_OK;
 }
 
@@ -420,7 +429,7 @@ int ifr_set_item_matrix_csr(ifr_handle h, const int64_t *indptr, const int32_t *
     h->ii_chunks = n_chunks;
     rc = set_col_scale(h, col_scale, n_items, (int64_t)n_chunks * chunk);
     if (rc) { clear_item_model(h); return rc; }
-    h->n_items = n_items; h->n_users = 0; h->mode = MODE_ITEM_CSR;
+    h->n_items = n_items; h->n_users = 0; h->mode = MODE_ITEM_CSR; h->opt_catalogue = 0;
     return IFR_OK;
 }
 
@@ -708,10 +717,11 @@ int ifr_auc_dense(ifr_handle h, const int32_t *user_ids, int64_t n, const float 
     if (!h) return IFR_ERR_ARG;
     if (!h->tr_ptr || h->n_items <= 0) return fail(h, IFR_ERR_STATE, "ifr_auc_dense: factors / truth CSR not set");
     if (n == 0) return IFR_OK;
-    if (!user_ids || !scores || !out_auc || n < 0 || ld < h->n_items) return fail(h, IFR_ERR_ARG, "ifr_auc_dense: bad argument");
+    const int64_t cat = catalogue_items(h);
+    if (!user_ids || !scores || !out_auc || n < 0 || ld < cat) return fail(h, IFR_ERR_ARG, "ifr_auc_dense: bad argument");
     if (h->tr_max_row > 8192) return fail(h, IFR_ERR_ARG, "ifr_auc_dense: more than 8192 positives in one row");
     IFR_HIP(h, hipSetDevice(h->device));
-    int rc = ifr::launch_auc(scores, ld, user_ids, n, (int)h->n_items, h->ex_ptr, h->ex_idx, h->ex_rows, h->tr_ptr,
+    int rc = ifr::launch_auc(scores, ld, user_ids, n, (int)cat, h->ex_ptr, h->ex_idx, h->ex_rows, h->tr_ptr,
                              h->tr_idx, h->tr_rows, out_auc, (hipStream_t)stream);
     if (rc) return fail(h, IFR_ERR_HIP, "ifr_auc_dense: launch failed");
     return IFR_OK;
@@ -723,11 +733,26 @@ int ifr_rank_full(ifr_handle h, const int32_t *user_ids, int64_t n, const float 
     if (!h) return IFR_ERR_ARG;
     if (h->n_items <= 0) return fail(h, IFR_ERR_STATE, "ifr_rank_full: factors not set");
     if (n == 0) return IFR_OK;
-    if (!user_ids || !scores || !out_ids || !n_cand || n < 0 || ld < h->n_items) return fail(h, IFR_ERR_ARG, "ifr_rank_full: bad argument");
+    const int64_t cat = catalogue_items(h);
+    if (!user_ids || !scores || !out_ids || !n_cand || n < 0 || ld < cat) return fail(h, IFR_ERR_ARG, "ifr_rank_full: bad argument");
     IFR_HIP(h, hipSetDevice(h->device));
-    int rc = ifr::launch_rank_full(scores, ld, user_ids, n, (int)h->n_items, h->ex_ptr, h->ex_idx, h->ex_rows, out_ids,
+    int rc = ifr::launch_rank_full(scores, ld, user_ids, n, (int)cat, h->ex_ptr, h->ex_idx, h->ex_rows, out_ids,
                                    n_cand, &h->ws_sort, &h->ws_sort_bytes, (hipStream_t)stream);
     if (rc) return fail(h, rc, "ifr_rank_full: sort failed");
+    return IFR_OK;
+}
+
+int ifr_pad_scores_min(ifr_handle h, float *scores, int64_t n, int64_t ld, void *stream)
+{
+    if (!h) return IFR_ERR_ARG;
+    if (h->n_items <= 0) return fail(h, IFR_ERR_STATE, "ifr_pad_scores_min: no model set");
+    const int64_t cat = catalogue_items(h);
+    if (n == 0 || cat == h->n_items) return IFR_OK;
+    if (!scores || n < 0 || ld < cat) return fail(h, IFR_ERR_ARG, "ifr_pad_scores_min: null argument or ld < catalogue_items");
+    IFR_HIP(h, hipSetDevice(h->device));
+    hipLaunchKernelGGL(ifr::pad_rows_min_kernel, dim3((unsigned)n), dim3(ifr::BLOCK), 0, (hipStream_t)stream, scores, ld,
+                       (int)h->n_items, (int)cat);
+    IFR_HIP(h, hipGetLastError());
     return IFR_OK;
 }
 

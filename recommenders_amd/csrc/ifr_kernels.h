@@ -685,6 +685,23 @@ __global__ __launch_bounds__(BLOCK) void metrics_list_kernel(ListMetricParams p)
     }
 }
 
+// Columns [n_known, n_cat) of every score row := the row's minimum over [0, n_known): items unknown to
+// the model get the user's minimum score (cornac/models/recommender.py:631-635).  NaN-free rows assumed
+// (fminf skips NaN like np.min does not; the reference's scores here are finite).
+__global__ __launch_bounds__(BLOCK) void pad_rows_min_kernel(float *scores, int64_t ld, int n_known, int n_cat)
+{
+    __shared__ float red[BLOCK / 64];
+    float *row = scores + (int64_t)blockIdx.x * ld;
+    float m = INFINITY;
+    for (int c = threadIdx.x; c < n_known; c += BLOCK) m = fminf(m, row[c]);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) m = fminf(m, __shfl_xor(m, off));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    m = fminf(fminf(red[0], red[1]), fminf(red[2], red[3]));
+    for (int c = n_known + threadIdx.x; c < n_cat; c += BLOCK) row[c] = m;
+}
+
 // column sums over evaluated users, two deterministic stages
 constexpr int COLSUM_ROWS = 256;
 __global__ __launch_bounds__(64) void colsum_kernel(const double *per_user, const int32_t *evaluated, int64_t n, int ncol,

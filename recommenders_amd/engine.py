@@ -101,6 +101,7 @@ class HipScorer:
         pib, kib = self._any_ptr(ibase, np.float32)
         self._check(self._lib.ifr_set_factors(self._h, pu, n_users, pv, n_items, k, pub, pib))
         self.n_users, self.n_items, self.k = int(n_users), int(n_items), int(k)
+        self.catalogue_items = self.n_items
         self.item_model = None
         del ku, kv, kub, kib
 
@@ -124,6 +125,7 @@ class HipScorer:
         pc, kc = self._any_ptr(col_scale, np.float32)
         self._check(self._lib.ifr_set_item_matrix_dense(self._h, pm, n_items, int(ld), pc))
         self.n_items, self.k, self.n_users = n_items, 0, 0
+        self.catalogue_items = n_items
         self.item_model = "dense"
         self.has_exclusions = False
         del km, kc
@@ -136,6 +138,7 @@ class HipScorer:
         pc, kc = self._any_ptr(col_scale, np.float32)
         self._check(self._lib.ifr_set_item_matrix_csr(self._h, pp, pi, pv, int(n_items), len(indices), pc))
         self.n_items, self.k, self.n_users = int(n_items), 0, 0
+        self.catalogue_items = self.n_items
         self.item_model = "csr"
         self.has_exclusions = False
         del kp, ki, kv, kc
@@ -227,13 +230,24 @@ class HipScorer:
                                              it.numel(), out.data_ptr(), self._stream()))
         return out
 
+    def set_catalogue_items(self, n_total):
+        """Rank / evaluate over n_total >= n_items items: the extra ones are unknown to the model and
+        score the user's minimum (recommender.py:631-635).  0 or n_items switches it off."""
+        n_total = int(n_total)
+        self._check(self._lib.ifr_set_option(self._h, b"catalogue_items", 0 if n_total == self.n_items else n_total))
+        self.catalogue_items = max(n_total, self.n_items)
+
     def score_dense(self, user_ids, out=None):
+        """Score rows [n, catalogue] (catalogue = n_items unless set_catalogue_items widened it)."""
         torch = _torch()
         u = self._dev_i32(user_ids)
         n = u.numel()
+        cols = max(getattr(self, "catalogue_items", 0), self.n_items)
         if out is None:
-            out = torch.empty((n, self.n_items), dtype=torch.float32, device=self.device)
+            out = torch.empty((n, cols), dtype=torch.float32, device=self.device)
         self._check(self._lib.ifr_score_dense(self._h, u.data_ptr(), n, out.data_ptr(), out.stride(0), self._stream()))
+        if cols > self.n_items:
+            self._check(self._lib.ifr_pad_scores_min(self._h, out.data_ptr(), n, out.stride(0), self._stream()))
         return out
 
     def auc_dense(self, user_ids, scores):

@@ -150,6 +150,26 @@ def plan_metrics(metrics):
     return specs, ks, need_auc, need_list
 
 
+def _append_unknown_items(ids, users, excl, n_known, n_items):
+    """Top-K lists of users with fewer than K known candidates continue with the unknown items
+    [n_known, n_items) that are not excluded, in ascending index (host bookkeeping: their order does
+    not depend on any score)."""
+    short = (ids < 0).any(dim=1).nonzero().flatten().cpu().numpy()
+    if len(short) == 0:
+        return ids
+    host = ids[short].cpu().numpy()
+    for r, row in zip(short, host):
+        u = int(users[r])
+        ex = excl[u].indices if u < excl.shape[0] else np.zeros(0, np.int64)
+        free = np.setdiff1d(np.arange(n_known, n_items), ex[ex >= n_known])
+        k0 = int((row >= 0).sum())
+        take = free[: len(row) - k0]
+        row[k0:k0 + len(take)] = take
+    ids = ids.clone()
+    ids[short] = ids.new_tensor(host)
+    return ids
+
+
 # --------------------------------------------------------------------------- ranking_eval
 def ranking_eval(model, metrics, train_set, test_set, val_set=None, rating_threshold=1.0, exclude_unknowns=True,
                  verbose=False, *, batch_pairs=1 << 28, distributed="auto", gather_user_results=True, _engine=None):
@@ -170,11 +190,12 @@ def ranking_eval(model, metrics, train_set, test_set, val_set=None, rating_thres
     eng = model._hip_engine() if _engine is None else _engine
 
     n_items = train_set.num_items if exclude_unknowns else test_set.num_items
-    if n_items != eng.n_items:
-        raise NotImplementedError(
-            f"ranking over {n_items} items but the model scores {eng.n_items}: exclude_unknowns=False with items "
-            "unknown to the model (min-score padding, recommender.py:631-635) is served by model.rank(), not by the "
-            "batched path yet")
+    if n_items < eng.n_items:
+        raise ValueError(f"ranking over {n_items} items but the model scores {eng.n_items}")
+    # n_items > eng.n_items: exclude_unknowns=False with items the model has never seen.  They score the
+    # user's minimum (recommender.py:631-635), i.e. they tie at the bottom and, having the largest
+    # indices, rank after every known candidate.
+    eng.set_catalogue_items(n_items)
     test_users = np.unique(np.asarray(test_set.uir_tuple[0]).astype(np.int64))
     n_rows = int(test_users.max()) + 1 if len(test_users) else 0
     truth, excl, has_pos = build_eval_csrs(train_set.csr_matrix, test_set.csr_matrix,
@@ -214,6 +235,8 @@ def ranking_eval(model, metrics, train_set, test_set, val_set=None, rating_thres
         if not need_list and ks:
             kmax = max(ks)
             ids, _ = eng.rank_topk(dev_users, kmax)
+            if n_items > eng.n_items:
+                ids = _append_unknown_items(ids, my_users, excl, eng.n_items, n_items)
             per_user, _, _ = eng.eval_topk_metrics(dev_users, ids, ks)
             per_user = per_user.cpu().numpy()
             for qi, k in enumerate(ks):

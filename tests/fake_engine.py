@@ -19,6 +19,7 @@ class OracleEngine:
         if self.ibase is None and self.ubase is not None:
             self.ibase = np.zeros(len(self.V), np.float32)
         self.n_users, self.n_items, self.k = len(self.U), len(self.V), self.U.shape[1]
+        self.catalogue_items = self.n_items
         self.device = torch.device("cpu")
         self.ex = (np.zeros(1, np.int64), np.zeros(0, np.int32))
         self.tr = (np.zeros(1, np.int64), np.zeros(0, np.int32))
@@ -33,12 +34,21 @@ class OracleEngine:
         ptr, idx = csr
         return idx[ptr[u]: ptr[u + 1]] if u + 1 < len(ptr) else idx[:0]
 
+    def set_catalogue_items(self, n_total):
+        self.catalogue_items = max(int(n_total), self.n_items)
+
     def _scores(self, u):
         ub = 0.0 if self.ubase is None else float(self.ubase[u])
         return orc.c_score_factor(self.U[u], self.V, self.ibase, ub, None)
 
+    def _padded(self, u):
+        s = self._scores(u)
+        if self.catalogue_items > self.n_items:      # recommender.py:631-635
+            s = np.concatenate([s, np.full(self.catalogue_items - self.n_items, s.min(), s.dtype)])
+        return s
+
     def score_dense(self, user_ids):
-        return torch.from_numpy(np.stack([self._scores(int(u)) for u in np.asarray(user_ids)]))
+        return torch.from_numpy(np.stack([self._padded(int(u)) for u in np.asarray(user_ids)]))
 
     def rank_topk(self, user_ids, K):
         users = np.asarray(user_ids)
@@ -54,11 +64,11 @@ class OracleEngine:
 
     def rank_full(self, user_ids, dense):
         users = np.asarray(user_ids)
-        out = np.full((len(users), self.n_items), -1, np.int32)
+        out = np.full((len(users), self.catalogue_items), -1, np.int32)
         n_cand = np.zeros(len(users), np.int32)
         d = dense.numpy()
         for r, u in enumerate(users):
-            cand = np.setdiff1d(np.arange(self.n_items), self._row(self.ex, int(u)))
+            cand = np.setdiff1d(np.arange(self.catalogue_items), self._row(self.ex, int(u)))
             out[r, : len(cand)] = orc.canonical_rank(cand, d[r][cand])
             n_cand[r] = len(cand)
         return torch.from_numpy(out), torch.from_numpy(n_cand)
@@ -107,7 +117,7 @@ class OracleEngine:
             pos = self._row(self.tr, int(u))
             if len(pos) == 0:
                 continue
-            cand = np.setdiff1d(np.arange(self.n_items), self._row(self.ex, int(u)))
+            cand = np.setdiff1d(np.arange(self.catalogue_items), self._row(self.ex, int(u)))
             out[r] = orc.auc(cand, d[r][cand], pos, np.setdiff1d(cand, pos))
         return torch.from_numpy(out)
 

@@ -157,13 +157,36 @@ def test_c1_config_bpr_k50(c1):
     np.testing.assert_allclose(avg, d["bpr__avg"], atol=1e-4, rtol=0)
 
 
-def test_unknown_items_are_rejected_loudly(unknowns):
+@pytest.mark.parametrize("name", ["mf", "bpr"])
+def test_unknown_items_and_users_match_reference(unknowns, name):
+    """exclude_unknowns=False: the min-score padding of recommender.py:631-635 and unknown users, batched."""
+    from collections import OrderedDict
     d = unknowns
     train_set, test_set, _ = _sets(d)
-    model = _model(d, "mf", train_set)
-    with pytest.raises(NotImplementedError):
-        ranking_eval(model, [M.NDCG(k=10)], train_set, test_set, rating_threshold=float(d["rating_threshold"]),
-                     exclude_unknowns=False)
+    model = _model(d, name, train_set)
+    # the reference's id maps are global (they also hold the ids only seen in the test split)
+    model.uid_map = OrderedDict((i, i) for i in range(int(d["total_users"])))
+    model.iid_map = OrderedDict((i, i) for i in range(int(d["total_items"])))
+    mets = _metrics(d)
+    avg, per = ranking_eval(model, mets, train_set, test_set, rating_threshold=float(d["rating_threshold"]),
+                            exclude_unknowns=False)
+    users = d[f"{name}__users"]
+    assert sorted(per[0].keys()) == users.tolist()
+    ref, tf = d[f"{name}__per_user"], _tie_free(d, name)
+    assert tf.mean() > 0.7
+    for j, mt in enumerate(mets):
+        got = np.asarray([per[j][int(u)] for u in users])
+        if mt.name == "AUC":
+            assert np.abs(got - ref[:, j]).max() < 1e-4 and abs(got.mean() - ref[:, j].mean()) < 1e-5
+        else:
+            np.testing.assert_allclose(got[tf], ref[tf][:, j], atol=1e-6, rtol=0)
+    np.testing.assert_allclose(avg, d[f"{name}__avg"], atol=5e-4, rtol=0)
+    # a lazily materialised full ranking covers the unknown items too, at the bottom
+    u = int(users[np.flatnonzero(tf)[0]])
+    r = np.flatnonzero(users == u)[0]
+    ranked = model.ranked_items[u]
+    assert len(ranked) == d[f"{name}__n_cand"][r]
+    np.testing.assert_array_equal(ranked[:19], d[f"{name}__ranked_head"][r][:19])
 
 
 def test_metric_objects_compute_like_the_reference():

@@ -225,3 +225,38 @@ def test_rp3_fit_builds_item_item_form_and_leaves_the_dataset_alone(toy):
     e = EASE(lamb=50, posB=True, trainable=True).fit(train_set)
     np.testing.assert_allclose(e.B, d["ease_B"], rtol=1e-9, atol=1e-12)
     np.testing.assert_array_equal(train_set.csr_matrix.data, before)
+
+
+@pytest.mark.parametrize("model", ["mf", "bpr"])
+def test_ranking_eval_with_unknown_items_and_users(unknowns, model):
+    """exclude_unknowns=False (fixture made by BaseMethod.from_splits): items the model has never seen
+    score the user's minimum and rank last (recommender.py:631-635), unknown users keep only the
+    item-side terms; per-user values equal the reference's."""
+    d = unknowns
+    train_set, test_set, _ = _datasets(d)
+    eng = _engine(d, model, test_set.num_users)
+    assert (eng.n_items < test_set.num_items) == (model == "mf")
+    mets = _spec_objects(d)
+    avg, per = ifr_eval.ranking_eval(types.SimpleNamespace(is_fitted=True), mets, train_set, test_set,
+                                     rating_threshold=float(d["rating_threshold"]), exclude_unknowns=False, _engine=eng)
+    users = d[f"{model}__users"]
+    assert sorted(per[0].keys()) == users.tolist()
+    ref, hs = d[f"{model}__per_user"], d[f"{model}__ranked_head_scores"]
+    gaps = np.abs(np.diff(hs, axis=1))
+    tie_free = (gaps > 1e-5 * np.maximum(1e-3, np.abs(hs[:, :-1]))).all(axis=1)
+    assert tie_free.mean() > 0.7
+    for j in range(len(mets)):
+        got = np.asarray([per[j][int(u)] for u in users])
+        if mets[j].name == "AUC":
+            assert np.abs(got - ref[:, j]).max() < 1e-4
+        else:
+            np.testing.assert_allclose(got[tie_free], ref[tie_free][:, j], atol=1e-9, rtol=0)
+    np.testing.assert_allclose(avg, d[f"{model}__avg"], atol=5e-4, rtol=0)
+
+
+def test_append_unknown_items_fills_short_lists():
+    import torch
+    ids = torch.tensor([[5, 2, -1, -1], [1, 2, 3, 4], [-1, -1, -1, -1]], dtype=torch.int32)
+    excl = sp.csr_matrix(np.array([[0, 0, 0, 0, 0, 0, 1, 0, 0], [0] * 9, [0, 0, 0, 0, 0, 0, 1, 1, 1]], dtype=np.int8))
+    out = ifr_eval._append_unknown_items(ids, np.array([0, 1, 2]), excl, 6, 9).numpy()
+    np.testing.assert_array_equal(out, [[5, 2, 7, 8], [1, 2, 3, 4], [-1, -1, -1, -1]])
