@@ -51,8 +51,8 @@ struct ifr_handle_s {
     double prof_bytes = 0.0;
     // exclusions: raw CSR (AUC / full rank) + tile-encoded lists (fused kernel)
     int64_t *ex_ptr = nullptr;
-    int32_t *ex_idx = nullptr, *ex_cnt = nullptr, *ex_tile = nullptr;
-    uint32_t *ex_mask = nullptr;
+    int32_t *ex_idx = nullptr, *ex_cnt = nullptr;
+    uint2 *ex_pair = nullptr;
     int64_t ex_rows = 0, ex_nnz = 0;
     // truth
     int64_t *tr_ptr = nullptr;
@@ -164,7 +164,7 @@ void clear_factor_model(ifr_handle h)
 void drop_csrs_if_catalogue_changes(ifr_handle h, int64_t n_items)
 {
     if (h->n_items == n_items) return;
-    dfree(h->ex_ptr); dfree(h->ex_idx); dfree(h->ex_cnt); dfree(h->ex_tile); dfree(h->ex_mask);
+    dfree(h->ex_ptr); dfree(h->ex_idx); dfree(h->ex_cnt); dfree(h->ex_pair);
     h->ex_rows = 0; h->ex_nnz = 0;
 }
 
@@ -228,7 +228,7 @@ int ifr_destroy(ifr_handle h)
     if (!h) return IFR_ERR_ARG;
     (void)hipSetDevice(h->device);
     dfree(h->U); dfree(h->V); dfree(h->ibase); dfree(h->ubase);
-    dfree(h->ex_ptr); dfree(h->ex_idx); dfree(h->ex_cnt); dfree(h->ex_tile); dfree(h->ex_mask);
+    dfree(h->ex_ptr); dfree(h->ex_idx); dfree(h->ex_cnt); dfree(h->ex_pair);
     dfree(h->tr_ptr); dfree(h->tr_idx); dfree(h->discount);
     dfree(h->iiM); dfree(h->ii_cptr); dfree(h->ii_idx); dfree(h->ii_val); dfree(h->ii_pen);
     dfree(h->hs_ptr); dfree(h->hs_idx); dfree(h->hs_val);
@@ -311,7 +311,7 @@ int ifr_set_exclusion_csr(ifr_handle h, const int64_t *indptr, const int32_t *in
 {
     if (!h) return IFR_ERR_ARG;
     IFR_HIP(h, hipSetDevice(h->device));
-    dfree(h->ex_ptr); dfree(h->ex_idx); dfree(h->ex_cnt); dfree(h->ex_tile); dfree(h->ex_mask);
+    dfree(h->ex_ptr); dfree(h->ex_idx); dfree(h->ex_cnt); dfree(h->ex_pair);
     h->ex_rows = 0; h->ex_nnz = 0;
     if (n_rows <= 0 || !indptr) return IFR_OK;
     if (nnz > 0 && !indices) return fail(h, IFR_ERR_ARG, "ifr_set_exclusion_csr: null indices");
@@ -320,11 +320,10 @@ int ifr_set_exclusion_csr(ifr_handle h, const int64_t *indptr, const int32_t *in
     int rc = copy_csr(h, indptr, indices, n_rows, nnz, &h->ex_ptr, &h->ex_idx, &hp);
     if (rc) return rc;
     IFR_HIP(h, hipMalloc((void **)&h->ex_cnt, sizeof(int32_t) * n_rows));
-    IFR_HIP(h, hipMalloc((void **)&h->ex_tile, sizeof(int32_t) * std::max<int64_t>(nnz, 1)));
-    IFR_HIP(h, hipMalloc((void **)&h->ex_mask, sizeof(uint32_t) * std::max<int64_t>(nnz, 1)));
+    IFR_HIP(h, hipMalloc((void **)&h->ex_pair, sizeof(uint2) * std::max<int64_t>(nnz, 1)));
     const int grid = (int)((n_rows + 255) / 256);
     hipLaunchKernelGGL(ifr::encode_exclusions_kernel, dim3(grid), dim3(256), 0, 0, h->ex_ptr, h->ex_idx, n_rows,
-                       (int)h->n_items, h->ex_cnt, h->ex_tile, h->ex_mask);
+                       (int)h->n_items, h->ex_cnt, h->ex_pair);
     IFR_HIP(h, hipGetLastError());
     IFR_HIP(h, hipDeviceSynchronize());
     h->ex_rows = n_rows; h->ex_nnz = nnz;
@@ -571,7 +570,7 @@ int ifr_rank_topk(ifr_handle h, const int32_t *user_ids, int64_t n, int K, int32
     p.U = h->U; p.V = h->V; p.ibase = h->ibase; p.ubase = h->ubase;
     p.user_ids = user_ids; p.n = n; p.n_items = (int)h->n_items; p.n_tiles = h->n_tiles;
     p.chunk_tiles = chunk_tiles; p.n_chunks = n_chunks; p.K = K;
-    p.ex_ptr = h->ex_ptr; p.ex_cnt = h->ex_cnt; p.ex_tile = h->ex_tile; p.ex_mask = h->ex_mask; p.ex_rows = h->ex_rows;
+    p.ex_ptr = h->ex_ptr; p.ex_cnt = h->ex_cnt; p.ex_pair = h->ex_pair; p.ex_rows = h->ex_rows;
     p.dbg = h->opt_debug;
     p.part_scores = (float *)h->ws_part;
     p.part_ids = (int32_t *)((char *)h->ws_part + entries * 4);

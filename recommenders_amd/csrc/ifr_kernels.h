@@ -41,8 +41,7 @@ struct TopkParams {
     int K;                   // requested list length (<= KL)
     const int64_t *ex_ptr;   // may be null
     const int32_t *ex_cnt;
-    const int32_t *ex_tile;
-    const uint32_t *ex_mask;
+    const uint2 *ex_pair;    // (tile, 32-bit mask) entries of a user at ex_ptr[u] .. ex_ptr[u] + ex_cnt[u]
     int64_t ex_rows;
     float *part_scores;      // [n_slots][n_chunks*2][KL]
     int32_t *part_ids;
@@ -142,19 +141,22 @@ __global__ __launch_bounds__(BLOCK, KD > 128 ? 1 : 2) void score_topk_kernel(Top
     const float ub = HAS_BASE ? p.ubase[uid] : 0.0f;
 
     // exclusion cursor: first (tile, mask) entry with tile >= t0
+    // (nt, nm) is the next entry, (nt2, nm2) the one after it: an entry is loaded at least one
+    // tile before it is needed, so advancing the cursor never waits on memory inside the sweep
     int64_t ex_cur = 0, ex_end = 0;
-    int nt = NO_TILE;
-    uint32_t nm = 0;
+    int nt = NO_TILE, nt2 = NO_TILE;
+    uint32_t nm = 0, nm2 = 0;
     if (p.ex_ptr != nullptr && uid < p.ex_rows) {
         const int64_t b = p.ex_ptr[uid];
         int lo = 0, hi = p.ex_cnt[uid];
         ex_end = b + hi;
         while (lo < hi) {
             const int mid = (lo + hi) >> 1;
-            if (p.ex_tile[b + mid] < t0) lo = mid + 1; else hi = mid;
+            if ((int)p.ex_pair[b + mid].x < t0) lo = mid + 1; else hi = mid;
         }
         ex_cur = b + lo;
-        if (ex_cur < ex_end) { nt = p.ex_tile[ex_cur]; nm = p.ex_mask[ex_cur]; }
+        if (ex_cur < ex_end) { const uint2 e = p.ex_pair[ex_cur]; nt = (int)e.x; nm = e.y; }
+        if (ex_cur + 1 < ex_end) { const uint2 e = p.ex_pair[ex_cur + 1]; nt2 = (int)e.x; nm2 = e.y; }
     }
 
     float ls[KL];
@@ -303,8 +305,9 @@ __global__ __launch_bounds__(BLOCK, KD > 128 ? 1 : 2) void score_topk_kernel(Top
         mC = 0;
         if (nt == t) {
             mC = nm;
+            nt = nt2; nm = nm2;
             ++ex_cur;
-            if (ex_cur < ex_end) { nt = p.ex_tile[ex_cur]; nm = p.ex_mask[ex_cur]; } else nt = NO_TILE;
+            if (ex_cur + 1 < ex_end) { const uint2 e = p.ex_pair[ex_cur + 1]; nt2 = (int)e.x; nm2 = e.y; } else nt2 = NO_TILE;
         }
         if (t == p.n_tiles - 1) {
             const int valid = p.n_items - t * TILE_I;       // 1..32
@@ -479,7 +482,7 @@ __global__ __launch_bounds__(BLOCK, 2) void score_dense_kernel(DenseParams p)
 // Exclusion CSR -> per-user (tile, mask) lists, written in place of the CSR row.
 // ------------------------------------------------------------------------------------
 __global__ void encode_exclusions_kernel(const int64_t *indptr, const int32_t *indices, int64_t n_rows,
-                                         int n_items, int32_t *ex_cnt, int32_t *ex_tile, uint32_t *ex_mask)
+                                         int n_items, int32_t *ex_cnt, uint2 *ex_pair)
 {
     const int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (u >= n_rows) return;
@@ -491,12 +494,12 @@ __global__ void encode_exclusions_kernel(const int64_t *indptr, const int32_t *i
         if (it < 0 || it >= n_items) continue;
         const int T = it >> 5;
         if (T != tile) {
-            if (tile >= 0) { ex_tile[b + c] = tile; ex_mask[b + c] = mask; ++c; }
+            if (tile >= 0) { ex_pair[b + c] = make_uint2((uint32_t)tile, mask); ++c; }
             tile = T; mask = 0;
         }
         mask |= 1u << (it & 31);
     }
-    if (tile >= 0) { ex_tile[b + c] = tile; ex_mask[b + c] = mask; ++c; }
+    if (tile >= 0) { ex_pair[b + c] = make_uint2((uint32_t)tile, mask); ++c; }
     ex_cnt[u] = c;
 }
 
