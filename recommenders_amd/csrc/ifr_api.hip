@@ -122,8 +122,9 @@ void pick_chunks(ifr_handle h, int64_t n, int *chunk_tiles, int *n_chunks)
 template <int KD, int KL>
 void launch_topk(bool has_base, const ifr::TopkParams &p, int grid, hipStream_t s)
 {
-    if (has_base) hipLaunchKernelGGL((ifr::score_topk_kernel<KD, KL, true>), dim3(grid), dim3(ifr::BLOCK), 0, s, p);
-    else hipLaunchKernelGGL((ifr::score_topk_kernel<KD, KL, false>), dim3(grid), dim3(ifr::BLOCK), 0, s, p);
+    const size_t pad = (p.dbg & 64) ? 30000 : 0;     // dev ablation: extra LDS -> one workgroup per CU
+    if (has_base) hipLaunchKernelGGL((ifr::score_topk_kernel<KD, KL, true>), dim3(grid), dim3(ifr::BLOCK), pad, s, p);
+    else hipLaunchKernelGGL((ifr::score_topk_kernel<KD, KL, false>), dim3(grid), dim3(ifr::BLOCK), pad, s, p);
 }
 
 template <int KL>
@@ -218,6 +219,7 @@ int ifr_create(ifr_handle *out, int device_id)
         return IFR_ERR_HIP;
     }
     if (const char *e = getenv("IFR_CHUNKS")) h->opt_chunks = atoi(e);
+    if (const char *e = getenv("IFR_DEBUG_MODE")) h->opt_debug = atoi(e);      // dev-only kernel ablation
     if (const char *e = getenv("IFR_TARGET_BLOCKS")) h->opt_target_blocks = std::max(1, atoi(e));
     *out = h;
     return IFR_OK;

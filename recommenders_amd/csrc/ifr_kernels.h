@@ -46,7 +46,8 @@ struct TopkParams {
     float *part_scores;      // [n_slots][n_chunks*2][KL]
     int32_t *part_ids;
     uint32_t *lb;            // [n_slots padded to 128] per-user lower-bound keys, zeroed per call (may be null)
-    int dbg;                 // dev-only ablation switch: 0 = normal, 1 = no select, 2 = filter only (never hits)
+    int dbg;                 // dev-only ablation switch, bits 0-2: 0 = normal, 2 = never hits, 3 = also no staging and no
+                             // barrier, 4 = no staging; bit 6 (host side): extra LDS so that one workgroup fits per CU
 };
 
 // item row inside a 32x32 accumulator block held by register r of a lane in half h
@@ -221,8 +222,9 @@ __global__ __launch_bounds__(BLOCK, KD > 128 ? 1 : 2) void score_topk_kernel(Top
     for (int r = 0; r < 16; ++r) ibC[r] = 0.0f;
     uint32_t mC = 0;
     for (int t = t0; t <= t1; ++t) {
-        const int buf = (t - t0) & 1;
-        if (t + 1 < t1) stage_load(t + 1);
+        const bool dbg_no_stage = (p.dbg & 7) >= 3;   // dev ablation: 3 = no staging, no barrier; 4 = no staging
+        const int buf = dbg_no_stage ? 0 : (t - t0) & 1;
+        if (t + 1 < t1 && !dbg_no_stage) stage_load(t + 1);
 
         // ---- zone A: 32 items x 32 users x KD on the matrix core (tile t), one k-group of four
         // MFMAs per step, each step followed by the branch-free part of the select for 128/KD score
@@ -235,7 +237,7 @@ __global__ __launch_bounds__(BLOCK, KD > 128 ? 1 : 2) void score_topk_kernel(Top
         f32x16 accN = {0};
         float ibN[16];
         const float *arow = &vt[buf][j][4 * h];
-        const float seltau = (t > t0 && p.dbg != 2) ? tau : INFINITY;
+        const float seltau = (t > t0 && (p.dbg & 7) < 2) ? tau : INFINITY;
         const int item0 = (t - 1) * TILE_I + 4 * h;
         const uint32_t mm = mC >> (4 * h);
         float s[16], gmx[4];
@@ -316,8 +318,8 @@ __global__ __launch_bounds__(BLOCK, KD > 128 ? 1 : 2) void score_topk_kernel(Top
         accC = accN;
 #pragma unroll
         for (int r = 0; r < 16; ++r) ibC[r] = ibN[r];
-        if (t + 1 < t1) stage_store(buf ^ 1);
-        __syncthreads();
+        if (t + 1 < t1 && !dbg_no_stage) stage_store(buf ^ 1);
+        if ((p.dbg & 7) != 3) __syncthreads();
     }
 
     // ---- final drain and write the lane's partial list

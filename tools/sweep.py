@@ -23,9 +23,11 @@ def main():
         torch.cuda.synchronize()
         ms, l, _ = sc.profile_read(); sc.profile_enable(False)
         print(f"{tag:40s} {ms/l:8.3f} ms  {flops/(ms/l*1e-3)/1e12:7.1f} TF", flush=True)
-    for dbg in (0, 2):
+    dbgs = [int(x) for x in os.environ.get("SWEEP_DBG", "0,2").split(",")]
+    chs = [int(x) for x in os.environ.get("SWEEP_CHUNKS", "1,2,3,4,6,8").split(",")]
+    for dbg in dbgs:
         sc.set_option("debug_mode", dbg)
-        for ch in (1, 2, 3, 4, 6, 8):
+        for ch in chs:
             sc.set_option("chunks", ch)
             run(f"dbg={dbg} chunks={ch}")
 main()
