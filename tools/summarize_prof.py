@@ -30,9 +30,12 @@ def main():
                                                "total_corrected": 2 * fr + wr}
         if "kernel_trace" in res:
             res["hbm_gbps_corrected"] = (2 * fr + wr) / res["kernel_trace"]["average_ns"]
-    if "SQ_VALU_MFMA_BUSY_CYCLES" in c and "SQ_BUSY_CYCLES" in c:
-        # MFMA busy is summed over the 4 SIMDs of every CU, SQ_BUSY_CYCLES over shader engines x XCDs
-        res["mfma_busy_per_wave_cycle"] = c["SQ_VALU_MFMA_BUSY_CYCLES"]["mean_per_launch"] / max(c["SQ_WAVE_CYCLES"]["mean_per_launch"], 1)
+    if "SQ_VALU_MFMA_BUSY_CYCLES" in c and "GRBM_GUI_ACTIVE" in c:
+        # MFMA busy cycles are summed over the 1024 SIMDs, GRBM_GUI_ACTIVE over the 8 XCDs
+        cycles = c["GRBM_GUI_ACTIVE"]["mean_per_launch"] / 8
+        res["mfma_busy_frac_of_simd_cycles"] = c["SQ_VALU_MFMA_BUSY_CYCLES"]["mean_per_launch"] / 1024 / cycles
+        if "kernel_trace" in res:
+            res["shader_clock_ghz"] = cycles / res["kernel_trace"]["average_ns"]
     print(json.dumps(res, indent=1))
 
 main()
