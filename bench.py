@@ -127,11 +127,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    # one rank per GPU; a rehearsal with more ranks than GPUs (IFR_BENCH_BACKEND=gloo on a one-GPU box) shares devices
+    local = local % max(1, torch.cuda.device_count())
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
+    if world > 1:
+        backend = os.environ.get("IFR_BENCH_BACKEND", "nccl")       # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     # each rank owns one user shard of the configured size (weak scaling); item-side parameters replicated
     item_model = args.config in synth.ITEM_CONFIGS
@@ -161,10 +166,20 @@ def main():
         sc.rank_topk(users, TOPK, ids, scores)
         per_user, evaluated, sums = sc.eval_topk_metrics(users, ids, [TOPK])
         if world > 1:
-            dist.all_reduce(sums)                      # RCCL: per-metric sums + evaluated-user count
+            sums = all_reduce(sums)                    # RCCL: per-metric sums + evaluated-user count
         h_ids.copy_(ids, non_blocking=True)
         h_scores.copy_(scores, non_blocking=True)
         return sums
+
+    def all_reduce(t, op=None):
+        """In place on the device with RCCL; through host memory in a gloo rehearsal."""
+        op = dist.ReduceOp.SUM if op is None else op
+        if dist.get_backend() == "nccl":
+            dist.all_reduce(t, op=op)
+            return t
+        c = t.cpu()
+        dist.all_reduce(c, op=op)
+        return c.to(t.device)
 
     def fence():
         torch.cuda.synchronize(dev)
@@ -184,8 +199,7 @@ def main():
     sc.profile_enable(False)
     kern_ms, launches, pairs = sc.profile_read()
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tmax = all_reduce(torch.tensor([dt], dtype=torch.float64, device=dev), dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
     if rank == 0:
