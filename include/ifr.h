@@ -60,6 +60,11 @@ int ifr_set_option(ifr_handle h, const char *name, int64_t value);
 int ifr_set_factors(ifr_handle h, const float *U, int64_t n_users, const float *V, int64_t n_items,
                     int k, const float *ubase, const float *ibase);
 
+/* Replace only the user side (query vectors) of a dot-product model, keeping the item factors on
+ * the device: the query of BaseANN.knn_query(query[B, d], k) (cornac/models/ann/recom_ann_base.py:
+ * 91-98), whose rows need not be rows of the model's user matrix.  k must equal the item factors'. */
+int ifr_set_user_factors(ifr_handle h, const float *U, int64_t n_users, int k, const float *ubase);
+
 /* Item-item models: score(u, :) = (sum_{j in hist(u)} x_uj * M[j, :]) * col_scale, the other model
  * family of the path.  Replaces the parameter reads of EASE.score (cornac/models/ease/recom_ease.py:
  * 123-124: M = B, hist(u) = row u of train_set.matrix with its ratings, col_scale NULL) and of

@@ -24,6 +24,7 @@ SIGNATURES = {
     "ifr_last_error": (ctypes.c_char_p, [vp]),
     "ifr_set_option": (ctypes.c_int, [vp, ctypes.c_char_p, ctypes.c_int64]),
     "ifr_set_factors": (ctypes.c_int, [vp, vp, ctypes.c_int64, vp, ctypes.c_int64, ctypes.c_int, vp, vp]),
+    "ifr_set_user_factors": (ctypes.c_int, [vp, vp, ctypes.c_int64, ctypes.c_int, vp]),
     "ifr_set_item_matrix_dense": (ctypes.c_int, [vp, vp, ctypes.c_int64, ctypes.c_int64, vp]),
     "ifr_set_item_matrix_csr": (ctypes.c_int, [vp, vp, vp, vp, ctypes.c_int64, ctypes.c_int64, vp]),
     "ifr_set_history_csr": (ctypes.c_int, [vp, vp, vp, vp, ctypes.c_int64, ctypes.c_int64]),

@@ -293,6 +293,26 @@ int ifr_set_factors(ifr_handle h, const float *U, int64_t n_users, const float *
     return IFR_OK;
 }
 
+int ifr_set_user_factors(ifr_handle h, const float *U, int64_t n_users, int k, const float *ubase)
+{
+    if (!h) return IFR_ERR_ARG;
+    if (h->mode != MODE_FACTOR) return fail(h, IFR_ERR_STATE, "ifr_set_user_factors: call ifr_set_factors first");
+    if (!U || n_users <= 0 || k != h->k) return fail(h, IFR_ERR_ARG, "ifr_set_user_factors: null/empty input or k differs from the item factors'");
+    if (ubase && !h->has_base) return fail(h, IFR_ERR_ARG, "ifr_set_user_factors: the model was set without bases");
+    IFR_HIP(h, hipSetDevice(h->device));
+    dfree(h->U); dfree(h->ubase);
+    h->n_users = 0;
+    const int KD = h->KD;
+    IFR_HIP(h, hipMalloc((void **)&h->U, sizeof(float) * n_users * KD));
+    IFR_HIP(h, hipMalloc((void **)&h->ubase, sizeof(float) * n_users));
+    IFR_HIP(h, hipMemset(h->U, 0, sizeof(float) * n_users * KD));
+    IFR_HIP(h, hipMemset(h->ubase, 0, sizeof(float) * n_users));
+    IFR_HIP(h, hipMemcpy2D(h->U, sizeof(float) * KD, U, sizeof(float) * k, sizeof(float) * k, n_users, hipMemcpyDefault));
+    if (ubase) IFR_HIP(h, hipMemcpy(h->ubase, ubase, sizeof(float) * n_users, hipMemcpyDefault));
+    h->n_users = n_users;
+    return IFR_OK;
+}
+
 static int copy_csr(ifr_handle h, const int64_t *indptr, const int32_t *indices, int64_t n_rows, int64_t nnz,
                     int64_t **d_ptr, int32_t **d_idx, std::vector<int64_t> *host_ptr)
 {

@@ -105,6 +105,15 @@ class HipScorer:
         self.item_model = None
         del ku, kv, kub, kib
 
+    def set_user_factors(self, U, ubase=None):
+        """Replace the user side (query vectors) only; the item factors stay on the device."""
+        n_users, k = U.shape
+        pu, ku = self._any_ptr(U, np.float32)
+        pub, kub = self._any_ptr(ubase, np.float32)
+        self._check(self._lib.ifr_set_user_factors(self._h, pu, n_users, k, pub))
+        self.n_users = int(n_users)
+        del ku, kub
+
     def set_item_matrix_dense(self, M, col_scale=None):
         """Item-item model with a dense M [I, I] (EASE's B, or a dense RP3-beta W); NumPy or torch."""
         n_items = int(M.shape[0])

@@ -247,6 +247,18 @@ class BPR(HipScoringMixin, RecommenderBase):
         return self.u_factors, self.i_factors, None, bi
 
     _hip_item_must_be_known = False     # BPR.score never raises (recom_bpr.pyx:290-297)
+    _ann_supported = True
+
+    def get_vector_measure(self):       # recom_bpr.pyx:299-307
+        return "dot"
+
+    def get_user_vectors(self):         # recom_bpr.pyx:309-320: [U, 1]
+        u = np.asarray(self.u_factors, np.float32)
+        return np.concatenate([u, np.ones([u.shape[0], 1], np.float32)], axis=1) if self.use_bias else u
+
+    def get_item_vectors(self):         # recom_bpr.pyx:322-333: [V, Bi]
+        v = np.asarray(self.i_factors, np.float32)
+        return np.concatenate([v, np.asarray(self.i_biases, np.float32).reshape(-1, 1)], axis=1) if self.use_bias else v
 
     def _hip_user_row(self, user_idx):
         return int(user_idx)            # factors are allocated for total_users (recom_bpr.pyx:146-151)

@@ -218,3 +218,42 @@ def test_metric_objects_compute_like_the_reference():
                                                                    int(c["pd_scores_linspace_desc"][2]))[::-1]
         exp = c["expect"] if "expect" in c else eval(c["expect_expr"])
         assert M.MAP().compute(A(c["item_indices"]), s, A(c["gt_pos"])) == pytest.approx(exp, abs=1e-15)
+
+
+def test_exact_ann_backend_matches_base_model(toy):
+    """HipExactANN behind the reference's BaseANN interface (knn_query / rank / recommend_batch,
+    cornac/models/ann/recom_ann_base.py:91-235): exact search returns what the base model's rank does."""
+    from recommenders_amd.ann import HipExactANN
+    d = toy
+    train_set, _, _ = _sets(d)
+    bpr = _model(d, "bpr", train_set)
+    bpr.train_set = train_set
+    ann = HipExactANN(bpr).fit(train_set)
+    assert ann.user_vectors.shape[1] == d["bpr_U"].shape[1] + 1            # bias folded in (recom_bpr.pyx:309-333)
+    users = np.array([0, 5, 17, 123])
+    for k in (10, 50):
+        ids, dist = ann.knn_query(ann.user_vectors[users], k)
+        assert ids.shape == dist.shape == (len(users), k) and (np.diff(dist, axis=1) >= 0).all()
+        S = ann.user_vectors[users].astype(np.float64) @ ann.item_vectors.astype(np.float64).T
+        for r in range(len(users)):
+            expect = np.lexsort((np.arange(S.shape[1]), -S[r]))[:k]
+            sep = np.abs(np.diff(S[r][expect])) > 1e-6
+            np.testing.assert_array_equal(ids[r][:-1][sep[:k - 1]], expect[:-1][sep[:k - 1]])
+            np.testing.assert_allclose(-dist[r], S[r][ids[r]], rtol=1e-5, atol=1e-6)
+    # arbitrary query vectors, not rows of the user matrix
+    q = np.random.default_rng(0).normal(size=(3, ann.user_vectors.shape[1])).astype(np.float32)
+    ids, dist = ann.knn_query(q, 5)
+    np.testing.assert_array_equal(ids, np.argsort(-(q.astype(np.float64) @ ann.item_vectors.T.astype(np.float64)), axis=1)[:, :5])
+    # rank(): neighbours first, the rest in index order with -inf (recom_ann_base.py:122-137)
+    ranked, scores = ann.rank(5, k=10)
+    base_ranked, base_scores = bpr.rank(5)
+    np.testing.assert_array_equal(ranked[:10], base_ranked[:10])
+    assert len(ranked) == ann.num_items and np.isneginf(scores).sum() == ann.num_items - 10
+    np.testing.assert_allclose(scores[ranked[:10]], base_scores[base_ranked[:10]], rtol=1e-5, atol=1e-6)
+    rec = ann.recommend_batch([ann.user_ids[5], ann.user_ids[0]], k=10)
+    assert rec[0] == [ann.item_ids[i] for i in base_ranked[:10]]
+    seen = set(train_set.csr_matrix.getrow(5).indices.tolist())
+    rec2 = ann.recommend_batch([ann.user_ids[5]], k=10, remove_seen=True, train_set=train_set)[0]
+    assert not (set(rec2) & seen) and set(rec2) <= set(rec[0])
+    with pytest.raises(ValueError):
+        ann.recommend_batch(["nobody"], k=3)
