@@ -116,6 +116,7 @@ def main():
     ap.add_argument("--items", type=int, default=None, help="override catalogue size (debug only)")
     ap.add_argument("--cpu-sample", type=int, default=None, help="users in the CPU baseline sample")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--auc", action="store_true", help="second variant of SURVEY.md 8d: also AUC (dense score rows + ifr_auc_dense)")
     args = ap.parse_args()
 
     import torch
@@ -162,9 +163,18 @@ def main():
     h_ids = torch.empty((n, TOPK), dtype=torch.int32).pin_memory()
     h_scores = torch.empty((n, TOPK), dtype=torch.float32).pin_memory()
 
+    auc_rows = max(1, min(n, (1 << 28) // w["n_items"])) if args.auc else 0
+    auc_buf = torch.empty((auc_rows, w["n_items"]), dtype=torch.float32, device=dev) if args.auc else None
+    auc_out = torch.empty((n,), dtype=torch.float64, device=dev) if args.auc else None
+
     def step():
         sc.rank_topk(users, TOPK, ids, scores)
         per_user, evaluated, sums = sc.eval_topk_metrics(users, ids, [TOPK])
+        if args.auc:
+            for b in range(0, n, auc_rows):
+                ub = users[b:b + auc_rows]
+                dense = sc.score_dense(ub, auc_buf[: ub.numel()])
+                auc_out[b:b + auc_rows] = sc.auc_dense(ub, dense)
         if world > 1:
             sums = all_reduce(sums)                    # RCCL: per-metric sums + evaluated-user count
         h_ids.copy_(ids, non_blocking=True)
@@ -247,9 +257,12 @@ def main():
             "data": "synthetic",
             "config": cfg,
             "roofline": roof,
+            "variant": "top-10 + NDCG/Recall/Precision@10" + (" + AUC (dense rows)" if args.auc else ""),
             "eval": {"ndcg@10": sums[0] / sums[-1], "recall@10": sums[1] / sums[-1],
                      "precision@10": sums[2] / sums[-1], "n_evaluated": float(sums[-1])},
         }
+        if args.auc:
+            out["eval"]["auc"] = float(torch.nanmean(auc_out).item())
         if world == 1 and not args.no_cpu:
             m = min(args.cpu_sample, n)
             if item_model:

@@ -49,6 +49,7 @@ struct ifr_handle_s {
     int64_t hs_rows = 0, hs_nnz = 0;
     float hs_l1max = 0.f;
     double prof_bytes = 0.0;
+    size_t dbg_stamp_count = 0;
     // exclusions: raw CSR (AUC / full rank) + tile-encoded lists (fused kernel)
     int64_t *ex_ptr = nullptr;
     int32_t *ex_idx = nullptr, *ex_cnt = nullptr;
@@ -594,6 +595,13 @@ int ifr_rank_topk(ifr_handle h, const int32_t *user_ids, int64_t n, int K, int32
     p.chunk_tiles = chunk_tiles; p.n_chunks = n_chunks; p.K = K;
     p.ex_ptr = h->ex_ptr; p.ex_cnt = h->ex_cnt; p.ex_pair = h->ex_pair; p.ex_rows = h->ex_rows;
     p.dbg = h->opt_debug;
+    p.stamps = nullptr;
+    if (h->opt_debug & 128) {                       // dev-only phase timing, read back by ifr_debug_read_stamps
+        int rc2 = grow(h, &h->ws_met, &h->ws_met_bytes, (size_t)grid * 4 * 8 * sizeof(unsigned long long));
+        if (rc2) return rc2;
+        p.stamps = (unsigned long long *)h->ws_met;
+        h->dbg_stamp_count = (size_t)grid * 32;
+    }
     p.part_scores = (float *)h->ws_part;
     p.part_ids = (int32_t *)((char *)h->ws_part + entries * 4);
     p.lb = h->opt_share_bounds ? (uint32_t *)((char *)h->ws_part + entries * 8) : nullptr;
@@ -800,6 +808,15 @@ int ifr_profile_read(ifr_handle h, double *kernel_ms, int64_t *launches, double 
     if (pairs_scored) *pairs_scored = h->prof_pairs;
     h->ev_used.clear();
     h->prof_pairs = 0.0;
+    return IFR_OK;
+}
+
+int ifr_debug_read_stamps(ifr_handle h, unsigned long long *out, int64_t cap, int64_t *n)
+{
+    if (!h || !out || !n) return IFR_ERR_ARG;
+    IFR_HIP(h, hipDeviceSynchronize());
+    *n = (int64_t)std::min<size_t>(h->dbg_stamp_count, (size_t)cap);
+    if (*n > 0) IFR_HIP(h, hipMemcpy(out, h->ws_met, sizeof(unsigned long long) * (size_t)*n, hipMemcpyDeviceToHost));
     return IFR_OK;
 }
 

@@ -46,6 +46,7 @@ struct TopkParams {
     float *part_scores;      // [n_slots][n_chunks*2][KL]
     int32_t *part_ids;
     uint32_t *lb;            // [n_slots padded to 128] per-user lower-bound keys, zeroed per call (may be null)
+    unsigned long long *stamps;  // dev-only: [grid][4 waves][8] cycle sums per phase (debug bit 7), else null
     int dbg;                 // dev-only ablation switch, bits 0-2: 0 = normal, 2 = never hits, 3 = also no staging and no
                              // barrier, 4 = no staging; bit 6 (host side): extra LDS so that one workgroup fits per CU
 };
@@ -216,12 +217,16 @@ __global__ __launch_bounds__(BLOCK, KD > 128 ? 1 : 2) void score_topk_kernel(Top
     // append), so the VALU/LDS work of the select fills the issue gaps of the matrix pipe.
     // Iteration t0 selects nothing (threshold +inf); iteration t1 multiplies a stale tile whose
     // result is dropped.
+    const bool dbg_stamp = (p.dbg & 128) && p.stamps != nullptr;
+    unsigned long long ph0 = 0, ph1 = 0, ph2 = 0, ph3 = 0, ph4 = 0, ph5 = 0, ph6 = 0;
     f32x16 accC = {0};
     float ibC[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) ibC[r] = 0.0f;
     uint32_t mC = 0;
     for (int t = t0; t <= t1; ++t) {
+        unsigned long long T0 = 0, T1 = 0, T2 = 0;
+        if (dbg_stamp) T0 = __builtin_amdgcn_s_memtime();
         const bool dbg_no_stage = (p.dbg & 7) >= 3;   // dev ablation: 3 = no staging, no barrier; 4 = no staging
         const int buf = dbg_no_stage ? 0 : (t - t0) & 1;
         if (t + 1 < t1 && !dbg_no_stage) stage_load(t + 1);
@@ -250,6 +255,7 @@ __global__ __launch_bounds__(BLOCK, KD > 128 ? 1 : 2) void score_topk_kernel(Top
                 const f32x4 b4 = *reinterpret_cast<const f32x4 *>(&ibt[buf][8 * g + 4 * h]);
                 ibN[4 * g + 0] = b4[0]; ibN[4 * g + 1] = b4[1]; ibN[4 * g + 2] = b4[2]; ibN[4 * g + 3] = b4[3];
             }
+            if (g == 0 && dbg_stamp) { asm volatile("" ::"v"(a_cur[0])); T1 = __builtin_amdgcn_s_memtime(); }
             accN = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[0], ureg[g][0], accN, 0, 0, 0);
             accN = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[1], ureg[g][1], accN, 0, 0, 0);
             accN = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[2], ureg[g][2], accN, 0, 0, 0);
@@ -270,9 +276,11 @@ __global__ __launch_bounds__(BLOCK, KD > 128 ? 1 : 2) void score_topk_kernel(Top
 #pragma unroll
             for (int r = 0; r < 16; ++r) ibN[r] = 0.0f;
         }
+        if (dbg_stamp) T2 = __builtin_amdgcn_s_memtime();
 
         // ---- zone B: threshold vote; only groups (4 registers) that hold a hit are scanned
         const float mx = fmaxf(fmaxf(gmx[0], gmx[1]), fmaxf(gmx[2], gmx[3]));
+        unsigned long long T2b = 0, T2c = 0;
         if (__any(mx > seltau)) {
             uint32_t todo = 0;                  // hits that found the lane's pending slots full
 #pragma unroll
@@ -291,6 +299,7 @@ __global__ __launch_bounds__(BLOCK, KD > 128 ? 1 : 2) void score_topk_kernel(Top
                     }
                 }
             }
+            if (dbg_stamp) T2b = __builtin_amdgcn_s_memtime();
             if (__any(todo != 0)) {
                 // drain every lane's pending slots into its register list, raise tau, retry the rest
                 flush();
@@ -302,6 +311,7 @@ __global__ __launch_bounds__(BLOCK, KD > 128 ? 1 : 2) void score_topk_kernel(Top
                     }
                 }
             }
+            if (dbg_stamp) T2c = __builtin_amdgcn_s_memtime();
         }
         // exclusion mask of tile t for the next iteration's select
         mC = 0;
@@ -320,6 +330,15 @@ __global__ __launch_bounds__(BLOCK, KD > 128 ? 1 : 2) void score_topk_kernel(Top
         for (int r = 0; r < 16; ++r) ibC[r] = ibN[r];
         if (t + 1 < t1 && !dbg_no_stage) stage_store(buf ^ 1);
         if ((p.dbg & 7) != 3) __syncthreads();
+        if (dbg_stamp) {
+            const unsigned long long T3 = __builtin_amdgcn_s_memtime();
+            ph0 += T1 - T0; ph1 += T2 - T1; ph2 += T3 - T2; ph3 += 1;
+            if (T2b) { ph4 += T2b - T2; ph5 += T2c - T2b; ph6 += 1; }
+        }
+    }
+    if (dbg_stamp && lane == 0) {
+        unsigned long long *o = p.stamps + ((int64_t)blockIdx.x * WAVES + wave) * 8;
+        o[0] = ph0; o[1] = ph1; o[2] = ph2; o[3] = ph3; o[4] = ph4; o[5] = ph5; o[6] = ph6; o[7] = 0;
     }
 
     // ---- final drain and write the lane's partial list
