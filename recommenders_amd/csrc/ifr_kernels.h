@@ -219,12 +219,11 @@ __global__ __launch_bounds__(BLOCK, KD > 128 ? 1 : 2) void score_topk_kernel(Top
     // result is dropped.
     const bool dbg_stamp = (p.dbg & 128) && p.stamps != nullptr;
     unsigned long long ph0 = 0, ph1 = 0, ph2 = 0, ph3 = 0, ph4 = 0, ph5 = 0, ph6 = 0;
-    f32x16 accC = {0};
-    float ibC[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) ibC[r] = 0.0f;
+    // Two accumulators take turns (tile t multiplies into one while the select reads tile t-1 from
+    // the other), so no register hand-over sits between the last MFMA of a tile and the next tile.
+    f32x16 accA = {0}, accB = {0};
     uint32_t mC = 0;
-    for (int t = t0; t <= t1; ++t) {
+    auto tile_step = [&](int t, const f32x16 &accC, f32x16 &accN) {
         unsigned long long T0 = 0, T1 = 0, T2 = 0;
         if (dbg_stamp) T0 = __builtin_amdgcn_s_memtime();
         const bool dbg_no_stage = (p.dbg & 7) >= 3;   // dev ablation: 3 = no staging, no barrier; 4 = no staging
@@ -233,27 +232,26 @@ __global__ __launch_bounds__(BLOCK, KD > 128 ? 1 : 2) void score_topk_kernel(Top
 
         // ---- zone A: 32 items x 32 users x KD on the matrix core (tile t), one k-group of four
         // MFMAs per step, each step followed by the branch-free part of the select for 128/KD score
-        // registers of tile t-1: bias add, exclusions (and rows past n_items) turned into NaN, which
-        // never compares '>', and a running max per 4-register group.  sched_barrier(0) keeps the
+        // registers of tile t-1: bias add and a running max per 4-register group.  sched_barrier(0) keeps the
         // steps apart so this VALU work issues while the step's last MFMA is still in the pipe.
         constexpr int G = KD / 8;               // k-groups per tile
         constexpr int SEL_G = G < 16 ? G : 16;  // k-groups that carry select work (KD = 256: the first 16)
         constexpr int RPG = 16 / SEL_G;         // score registers selected per such k-group
-        f32x16 accN = {0};
-        float ibN[16];
+        accN = f32x16{0};
         const float *arow = &vt[buf][j][4 * h];
         const float seltau = (t > t0 && (p.dbg & 7) < 2) ? tau : INFINITY;
         const int item0 = (t - 1) * TILE_I + 4 * h;
         const uint32_t mm = mC >> (4 * h);
-        float s[16], gmx[4];
+        float s[16], gmx[4], ibC[16];
         f32x4 a_cur = *reinterpret_cast<const f32x4 *>(arow);
 #pragma unroll
         for (int g = 0; g < G; ++g) {
             f32x4 a_nxt = a_cur;
             if (g + 1 < G) a_nxt = *reinterpret_cast<const f32x4 *>(arow + 8 * (g + 1));
             if (HAS_BASE && g < 4) {
-                const f32x4 b4 = *reinterpret_cast<const f32x4 *>(&ibt[buf][8 * g + 4 * h]);
-                ibN[4 * g + 0] = b4[0]; ibN[4 * g + 1] = b4[1]; ibN[4 * g + 2] = b4[2]; ibN[4 * g + 3] = b4[3];
+                // item bases of tile t-1: its LDS buffer is still intact (it is restaged after zone B)
+                const f32x4 b4 = *reinterpret_cast<const f32x4 *>(&ibt[buf ^ 1][8 * g + 4 * h]);
+                ibC[4 * g + 0] = b4[0]; ibC[4 * g + 1] = b4[1]; ibC[4 * g + 2] = b4[2]; ibC[4 * g + 3] = b4[3];
             }
             if (g == 0 && dbg_stamp) { asm volatile("" ::"v"(a_cur[0])); T1 = __builtin_amdgcn_s_memtime(); }
             accN = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[0], ureg[g][0], accN, 0, 0, 0);
@@ -262,19 +260,12 @@ __global__ __launch_bounds__(BLOCK, KD > 128 ? 1 : 2) void score_topk_kernel(Top
             accN = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[3], ureg[g][3], accN, 0, 0, 0);
 #pragma unroll
             for (int r = g * RPG; r < (g < SEL_G ? (g + 1) * RPG : 0); ++r) {
-                const int bit = (r & 3) + 8 * (r >> 2);
-                float sc = HAS_BASE ? ((ibC[r] + ub) + accC[r]) : accC[r];      // (ibase + ubase) + dot
-                const uint32_t kill = (uint32_t)(-(int32_t)((mm >> bit) & 1u)); // 0 or ~0
-                sc = __uint_as_float(__float_as_uint(sc) | (kill & 0xFFC00000u));
+                const float sc = HAS_BASE ? ((ibC[r] + ub) + accC[r]) : accC[r]; // (ibase + ubase) + dot
                 s[r] = sc;
                 gmx[r >> 2] = (r & 3) ? fmaxf(gmx[r >> 2], sc) : sc;            // max of each 4-register group
             }
             a_cur = a_nxt;
             __builtin_amdgcn_sched_barrier(0);
-        }
-        if (!HAS_BASE) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) ibN[r] = 0.0f;
         }
         if (dbg_stamp) T2 = __builtin_amdgcn_s_memtime();
 
@@ -288,7 +279,9 @@ __global__ __launch_bounds__(BLOCK, KD > 128 ? 1 : 2) void score_topk_kernel(Top
                 if (gmx[q] > seltau) {
 #pragma unroll
                     for (int r = 4 * q; r < 4 * q + 4; ++r) {
-                        if (s[r] > seltau) {
+                        // exclusions (and rows past n_items) are dropped here, on the rare path: the
+                        // fp32 MFMA shares the VALU, so a per-score kill in zone A is paid on every tile
+                        if (s[r] > seltau && !((mm >> ((r & 3) + 8 * q)) & 1u)) {
                             if (cnt < PEND) {
                                 pend[cnt][tid] = make_uint2(__float_as_uint(s[r]), (uint32_t)(item0 + (r & 3) + 8 * q));
                                 ++cnt;
@@ -325,9 +318,6 @@ __global__ __launch_bounds__(BLOCK, KD > 128 ? 1 : 2) void score_topk_kernel(Top
             const int valid = p.n_items - t * TILE_I;       // 1..32
             if (valid < 32) mC |= ~0u << valid;
         }
-        accC = accN;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) ibC[r] = ibN[r];
         if (t + 1 < t1 && !dbg_no_stage) stage_store(buf ^ 1);
         if ((p.dbg & 7) != 3) __syncthreads();
         if (dbg_stamp) {
@@ -335,6 +325,10 @@ __global__ __launch_bounds__(BLOCK, KD > 128 ? 1 : 2) void score_topk_kernel(Top
             ph0 += T1 - T0; ph1 += T2 - T1; ph2 += T3 - T2; ph3 += 1;
             if (T2b) { ph4 += T2b - T2; ph5 += T2c - T2b; ph6 += 1; }
         }
+    };
+    for (int t = t0; t <= t1; t += 2) {
+        tile_step(t, accA, accB);
+        if (t + 1 <= t1) tile_step(t + 1, accB, accA);
     }
     if (dbg_stamp && lane == 0) {
         unsigned long long *o = p.stamps + ((int64_t)blockIdx.x * WAVES + wave) * 8;
