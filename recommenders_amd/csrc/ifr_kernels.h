@@ -93,6 +93,15 @@ __device__ __forceinline__ void list_insert(float (&ls)[KL], int (&li)[KL], floa
     ls[0] = fmaxf(x, ls[0]);
 }
 
+// max of three without the canonicalising self-max that fmaxf() costs per operand (NaN operands
+// cannot make a finite result larger, and a NaN result never passes the '>' tests that follow)
+__device__ __forceinline__ float max3_raw(float a, float b, float c)
+{
+    float d;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+
 template <int KL>
 __device__ __forceinline__ float list_tau(const float (&ls)[KL], int K)
 {
@@ -181,10 +190,15 @@ __global__ __launch_bounds__(BLOCK, KD > 128 ? 1 : 2) void score_topk_kernel(Top
             list_insert<KL>(ls, li, x, (int)e.y);
         }
         cnt = 0;
+        // Lower bounds on the user's K-th best score: this lane's K-th best, the partner half-lane's,
+        // and min(ceil(K/2)-th best of both halves) -- the two lists hold distinct items, so at least K
+        // of the user's items reach it; for two random halves it is close to the K-th best of their
+        // union, about twice as selective as either K-th best alone.
         const float own = list_tau<KL>(ls, p.K);
-        float ext = __shfl_xor(own, 32);
+        const float ownh = list_tau<KL>(ls, (p.K + 1) >> 1);
+        float ext = fmaxf(__shfl_xor(own, 32), fminf(ownh, __shfl_xor(ownh, 32)));
         if (p.lb != nullptr) {
-            const uint32_t old = atomicMax(&p.lb[slot], float_to_key(own));
+            const uint32_t old = atomicMax(&p.lb[slot], float_to_key(fmaxf(own, ext)));
             ext = fmaxf(ext, key_to_float(old));
         }
         tau = fmaxf(fmaxf(own, next_below(ext)), tau);
@@ -194,10 +208,13 @@ __global__ __launch_bounds__(BLOCK, KD > 128 ? 1 : 2) void score_topk_kernel(Top
     f32x4 st[STAGE];
     float st_b = 0.0f;
     auto stage_load = [&](int t) {
-        const float *src = p.V + (int64_t)t * TILE_I * KD;
+        // uniform tile base (SGPRs) + 32-bit per-thread byte offset: the scalar-base form of
+        // global_load, no 64-bit VALU address arithmetic per tile
+        const char *src = reinterpret_cast<const char *>(p.V) + (int64_t)t * (TILE_I * KD * 4);
+        const uint32_t off = (uint32_t)tid * 16u;
 #pragma unroll
         for (int q = 0; q < STAGE; ++q)
-            st[q] = *reinterpret_cast<const f32x4 *>(src + (int64_t)(tid + q * BLOCK) * 4);
+            st[q] = *reinterpret_cast<const f32x4 *>(src + (off + (uint32_t)(q * BLOCK * 16)));
         if (HAS_BASE && tid < TILE_I) st_b = p.ibase[t * TILE_I + tid];
     };
     auto stage_store = [&](int buf) {
@@ -217,7 +234,11 @@ __global__ __launch_bounds__(BLOCK, KD > 128 ? 1 : 2) void score_topk_kernel(Top
     // append), so the VALU/LDS work of the select fills the issue gaps of the matrix pipe.
     // Iteration t0 selects nothing (threshold +inf); iteration t1 multiplies a stale tile whose
     // result is dropped.
-    const bool dbg_stamp = (p.dbg & 128) && p.stamps != nullptr;
+#ifdef IFR_STAMPS
+    const bool dbg_stamp = (p.dbg & 128) && p.stamps != nullptr;       // make STAMPS=1: dev-only phase timing
+#else
+    constexpr bool dbg_stamp = false;
+#endif
     unsigned long long ph0 = 0, ph1 = 0, ph2 = 0, ph3 = 0, ph4 = 0, ph5 = 0, ph6 = 0;
     // Two accumulators take turns (tile t multiplies into one while the select reads tile t-1 from
     // the other), so no register hand-over sits between the last MFMA of a tile and the next tile.
@@ -262,7 +283,8 @@ __global__ __launch_bounds__(BLOCK, KD > 128 ? 1 : 2) void score_topk_kernel(Top
             for (int r = g * RPG; r < (g < SEL_G ? (g + 1) * RPG : 0); ++r) {
                 const float sc = HAS_BASE ? ((ibC[r] + ub) + accC[r]) : accC[r]; // (ibase + ubase) + dot
                 s[r] = sc;
-                gmx[r >> 2] = (r & 3) ? fmaxf(gmx[r >> 2], sc) : sc;            // max of each 4-register group
+                if ((r & 3) == 3)                                               // max of each 4-register group
+                    gmx[r >> 2] = max3_raw(max3_raw(s[r - 3], s[r - 2], s[r - 1]), sc, sc);
             }
             a_cur = a_nxt;
             __builtin_amdgcn_sched_barrier(0);
@@ -270,7 +292,7 @@ __global__ __launch_bounds__(BLOCK, KD > 128 ? 1 : 2) void score_topk_kernel(Top
         if (dbg_stamp) T2 = __builtin_amdgcn_s_memtime();
 
         // ---- zone B: threshold vote; only groups (4 registers) that hold a hit are scanned
-        const float mx = fmaxf(fmaxf(gmx[0], gmx[1]), fmaxf(gmx[2], gmx[3]));
+        const float mx = max3_raw(max3_raw(gmx[0], gmx[1], gmx[2]), gmx[3], gmx[3]);
         unsigned long long T2b = 0, T2c = 0;
         if (__any(mx > seltau)) {
             uint32_t todo = 0;                  // hits that found the lane's pending slots full
@@ -443,10 +465,13 @@ __global__ __launch_bounds__(BLOCK, 2) void score_dense_kernel(DenseParams p)
     f32x4 st[STAGE];
     float st_b = 0.0f;
     auto stage_load = [&](int t) {
-        const float *src = p.V + (int64_t)t * TILE_I * KD;
+        // uniform tile base (SGPRs) + 32-bit per-thread byte offset: the scalar-base form of
+        // global_load, no 64-bit VALU address arithmetic per tile
+        const char *src = reinterpret_cast<const char *>(p.V) + (int64_t)t * (TILE_I * KD * 4);
+        const uint32_t off = (uint32_t)tid * 16u;
 #pragma unroll
         for (int q = 0; q < STAGE; ++q)
-            st[q] = *reinterpret_cast<const f32x4 *>(src + (int64_t)(tid + q * BLOCK) * 4);
+            st[q] = *reinterpret_cast<const f32x4 *>(src + (off + (uint32_t)(q * BLOCK * 16)));
         if (HAS_BASE && tid < TILE_I) st_b = p.ibase[t * TILE_I + tid];
     };
     auto stage_store = [&](int buf) {
