@@ -1,4 +1,5 @@
-"""Dev tool: per-phase cycle split of the fused kernel's tile loop (debug bit 7, s_memtime stamps)."""
+"""Dev tool: per-phase cycle split of the fused kernel's tile loop (debug bit 7, s_memtime stamps).
+Needs a library built with the stamps compiled in: make -C recommenders_amd/csrc clean all STAMPS=1."""
 import sys, os, ctypes
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
