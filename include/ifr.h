@@ -77,7 +77,9 @@ int ifr_set_user_factors(ifr_handle h, const float *U, int64_t n_users, int k, c
  *   csr:    rows of M with strictly ascending columns.  Products are exact (fp64), scaled by
  *           2^shift (ifr_item_fixed_point_shift), rounded to nearest even and summed as 64-bit
  *           integers, so the result does not depend on summation order; the sum is rounded once
- *           to fp64, once to fp32 and multiplied by col_scale in fp32.
+ *           to fp64 and once to fp32.  col_scale is folded into the stored values when the matrix
+ *           is set (M'[j,c] = fl32(M[j,c] * col_scale[c])); a score that is exactly 0 is still
+ *           multiplied by col_scale[c], so that 0 * inf = NaN as in the reference.
  * col_scale: [n_items] or NULL.  "any" pointers. */
 int ifr_set_item_matrix_dense(ifr_handle h, const float *M, int64_t n_items, int64_t ld, const float *col_scale);
 int ifr_set_item_matrix_csr(ifr_handle h, const int64_t *indptr, const int32_t *indices, const float *values,

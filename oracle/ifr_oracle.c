@@ -270,9 +270,10 @@ int orc_ranking_eval_factor(
 /* (include/ifr.h) so that it can be compared bit-for-bit:              */
 /*  dense: per item one fp32 fma chain over the history in CSR order,   */
 /*         then one fp32 multiply by col_scale;                         */
-/*  csr:   exact fp64 products scaled by 2^shift, rounded to nearest    */
+/*  csr:   col_scale folded into the values (fl32(M * col_scale)),      */
+/*         exact fp64 products scaled by 2^shift, rounded to nearest    */
 /*         even, summed as int64 (order-free), rounded to fp64, to      */
-/*         fp32, then multiplied by col_scale in fp32.                  */
+/*         fp32; an exact 0 is still multiplied by col_scale.           */
 /* tests/test_oracle.py pins both against the reference's own EASE and  */
 /* RP3 outputs (tests/golden/toy_all_models.npz) within 1e-5 relative.  */
 /* ------------------------------------------------------------------ */
@@ -299,14 +300,15 @@ int orc_score_item_csr(const int64_t *m_ptr, const int32_t *m_idx, const float *
         const double x = (double)h_val[e];
         const int j = h_idx[e];
         for (int64_t q = m_ptr[j]; q < m_ptr[j + 1]; ++q) {
-            const double pr = x * (double)m_val[q];              /* exact */
+            const float w = col_scale ? m_val[q] * col_scale[m_idx[q]] : m_val[q];   /* folded, one fp32 rounding */
+            const double pr = x * (double)w;                     /* exact */
             acc[m_idx[q]] += llrint(ldexp(pr, shift));           /* nearest even */
         }
     }
     for (int c = 0; c < n_items; ++c) {
         if (acc[c] > ((int64_t)1 << 62) || acc[c] < -((int64_t)1 << 62)) rc = -1;
         const float s = (float)ldexp((double)acc[c], -shift);
-        out[c] = col_scale ? s * col_scale[c] : s;
+        out[c] = (col_scale && s == 0.0f) ? s * col_scale[c] : s;    /* 0 * inf = NaN like the reference */
     }
     free(acc);
     return rc;

@@ -426,11 +426,15 @@ def c_ranking_eval_item(M, m_csr, shift, n_items, col_scale, h_ptr, h_idx, h_val
     return ids, sc, met, ev
 
 
-def item_fixed_point_shift(m_val, h_ptr, h_val):
+def item_fixed_point_shift(m_val, h_ptr, h_val, m_idx=None, col_scale=None):
     """The shift rule documented in include/ifr.h (ifr_item_fixed_point_shift): the largest power of
-    two such that max|M| * max_u sum_j |x_uj| * 1.001 * 2^shift <= 2^61."""
+    two such that max|M'| * max_u sum_j |x_uj| * 1.001 * 2^shift <= 2^61, M' = the values with the
+    column scale folded in."""
     import math
-    maxabs = float(np.max(np.abs(np.asarray(m_val, np.float32)))) if len(m_val) else 0.0
+    m_val = np.asarray(m_val, np.float32)
+    if col_scale is not None:
+        m_val = (m_val * np.asarray(col_scale, np.float32)[np.asarray(m_idx)]).astype(np.float32)
+    maxabs = float(np.max(np.abs(m_val))) if len(m_val) else 0.0
     h_ptr = np.asarray(h_ptr, np.int64)
     l1 = np.add.reduceat(np.abs(np.asarray(h_val, np.float64)), h_ptr[:-1][np.diff(h_ptr) > 0]) if len(h_val) else np.zeros(0)
     l1max = float(np.nextafter(np.float32(l1.max()), np.float32(np.inf))) if len(l1) else 0.0

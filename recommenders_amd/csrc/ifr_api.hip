@@ -70,6 +70,7 @@ struct ifr_handle_s {
     int opt_target_blocks = 4096;
     int opt_share_bounds = 1;    // share per-user lower bounds between item chunks
     int opt_debug = 0;           // dev-only kernel ablation mode (see TopkParams::dbg)
+    int opt_csr_pass = 0;        // dev/test: entries per hash pass of the CSR top-K kernel (0 = the kernel's capacity)
     int64_t opt_catalogue = 0;   // items the dense-row consumers rank (0 = n_items; > n_items: items unknown to the model)
     // profiling
     bool prof = false;
@@ -250,6 +251,7 @@ int ifr_set_option(ifr_handle h, const char *name, int64_t value)
     if (!strcmp(name, "chunks")) h->opt_chunks = (int)value;
     else if (!strcmp(name, "share_bounds")) h->opt_share_bounds = (int)value;
     else if (!strcmp(name, "debug_mode")) h->opt_debug = (int)value;
+    else if (!strcmp(name, "csr_pass_entries")) h->opt_csr_pass = (int)std::max<int64_t>(0, std::min<int64_t>(value, ifr::item_sparse_pass_capacity()));
     else if (!strcmp(name, "catalogue_items")) {
         if (value != 0 && (value < h->n_items || value > (int64_t)1 << 30))
             return fail(h, IFR_ERR_ARG, "catalogue_items must be 0 or >= the model's n_items");
@@ -430,8 +432,17 @@ int ifr_set_item_matrix_csr(ifr_handle h, const int64_t *indptr, const int32_t *
     }
     int lrc = ifr::launch_validate_csr(d_ptr, h->ii_idx, n_items, (int)n_items, 1, d_flags, 0);
     uint32_t flags[2] = {0, 0};
-    if (!lrc) lrc = ifr::launch_build_chunk_ptr(d_ptr, h->ii_idx, n_items, n_chunks, chunk, h->ii_cptr, 0);
-    if (!lrc && nnz > 0) lrc = ifr::launch_absmax(h->ii_val, nnz, (uint32_t *)d_flags + 1, 0);
+    if (!lrc && (hipDeviceSynchronize() != hipSuccess ||
+                 hipMemcpy(flags, d_flags, sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess)) lrc = -3;
+    if (!lrc && flags[0] == 0) {                 // indices are safe to use from here on
+        lrc = ifr::launch_build_chunk_ptr(d_ptr, h->ii_idx, n_items, n_chunks, chunk, h->ii_cptr, 0);
+        if (!lrc && col_scale) {                 // fold the column scale into the values (one fp32 rounding each)
+            int rc2 = set_col_scale(h, col_scale, n_items, (int64_t)n_chunks * chunk);
+            if (rc2) { cleanup(); clear_item_model(h); return rc2; }
+            if (nnz > 0) lrc = ifr::launch_scale_csr_values(h->ii_val, h->ii_idx, nnz, h->ii_pen, 0);
+        }
+        if (!lrc && nnz > 0) lrc = ifr::launch_absmax(h->ii_val, nnz, (uint32_t *)d_flags + 1, 0);
+    }
     if (lrc || hipDeviceSynchronize() != hipSuccess ||
         hipMemcpy(flags, d_flags, sizeof(flags), hipMemcpyDeviceToHost) != hipSuccess) {
         cleanup(); clear_item_model(h);
@@ -444,13 +455,11 @@ int ifr_set_item_matrix_csr(ifr_handle h, const int64_t *indptr, const int32_t *
         clear_item_model(h);
         return fail(h, IFR_ERR_ARG, flags[0] & 1 ? "ifr_set_item_matrix_csr: column index outside [0, n_items)"
                                     : flags[0] & 2 ? "ifr_set_item_matrix_csr: columns of a row are not strictly ascending"
-                                                   : "ifr_set_item_matrix_csr: non-finite value");
+                                                   : "ifr_set_item_matrix_csr: non-finite value (after the column scale)");
     }
     h->ii_maxabs = maxabs;
     h->ii_nnz = nnz;
     h->ii_chunks = n_chunks;
-    rc = set_col_scale(h, col_scale, n_items, (int64_t)n_chunks * chunk);
-    if (rc) { clear_item_model(h); return rc; }
     h->n_items = n_items; h->n_users = 0; h->mode = MODE_ITEM_CSR; h->opt_catalogue = 0;
     return IFR_OK;
 }
@@ -507,6 +516,8 @@ static int item_item_params(ifr_handle h, const int32_t *user_ids, int64_t n, if
     p->M = h->iiM; p->ldm = h->ii_ld;
     p->cptr = h->ii_cptr; p->m_idx = h->ii_idx; p->m_val = h->ii_val; p->m_nnz = h->ii_nnz;
     p->fx_shift = h->mode == MODE_ITEM_CSR ? fixed_point_shift(h) : 0;
+    p->dbg = h->opt_debug;
+    p->sp_cap = h->opt_csr_pass > 0 ? h->opt_csr_pass : ifr::item_sparse_pass_capacity();
     p->pen = h->ii_pen;
     p->h_ptr = h->hs_ptr; p->h_idx = h->hs_idx; p->h_val = h->hs_val; p->h_rows = h->hs_rows;
     p->user_ids = user_ids; p->n = n; p->n_items = (int)h->n_items; p->n_chunks = h->ii_chunks;
@@ -542,6 +553,8 @@ static int rank_topk_item_item(ifr_handle h, const int32_t *user_ids, int64_t n,
     p.K = K; p.KL = KL;
     std::pair<hipEvent_t, hipEvent_t> ev;
     if (h->mode == MODE_ITEM_CSR) {                  // one workgroup per user, final lists written directly
+        if (p.n_chunks > ifr::item_sparse_max_chunks())
+            return fail(h, IFR_ERR_ARG, "ifr_rank_topk: CSR item matrix: catalogue beyond 2097152 items (use the dense-row entry points)");
         rc = prof_begin(h, s, &ev);
         if (rc) return rc;
         if (ifr::launch_item_sparse_topk(p, out_ids, out_scores, s)) return fail(h, IFR_ERR_HIP, "ifr_rank_topk: item-item launch failed");

@@ -13,7 +13,10 @@ struct ItemItemParams {
     const float *m_val;
     int64_t m_nnz;               //         entries in m_idx / m_val
     int fx_shift;                //         fixed-point scale 2^fx_shift
-    const float *pen;            // [>= n_chunks * chunk] column scale or null
+    int dbg;                     // dev-only ablation bits (handle option debug_mode)
+    int sp_cap;                  //         CSR top-K: entries one hash pass may hold (<= item_sparse_pass_capacity())
+    const float *pen;            // [>= n_chunks * chunk] column scale or null (CSR: already folded into m_val,
+                                 // kept for the 0 * col_scale = NaN rule of exact zeros)
     const int64_t *h_ptr;        // history CSR
     const int32_t *h_idx;
     const float *h_val;
@@ -34,12 +37,15 @@ struct ItemItemParams {
 
 int launch_item_item(const ItemItemParams &p, bool sparse, bool topk, hipStream_t stream);
 int launch_item_sparse_topk(const ItemItemParams &p, int32_t *out_ids, float *out_scores, hipStream_t stream);
+int item_sparse_pass_capacity();
+int item_sparse_max_chunks();
 int item_item_chunk(bool sparse);
 int item_item_pass();
 int launch_validate_csr(const int64_t *ptr, const int32_t *idx, int64_t n_rows, int n_cols, int need_sorted, int *bad,
                         hipStream_t s);
 int launch_build_chunk_ptr(const int64_t *ptr, const int32_t *idx, int64_t n_rows, int n_chunks, int chunk, int64_t *cptr,
                            hipStream_t s);
+int launch_scale_csr_values(float *val, const int32_t *idx, int64_t nnz, const float *col_scale, hipStream_t s);
 int launch_absmax(const float *x, int64_t n, uint32_t *out, hipStream_t s);
 int launch_row_l1_max(const int64_t *ptr, const float *val, int64_t n_rows, uint32_t *out, hipStream_t s);
 

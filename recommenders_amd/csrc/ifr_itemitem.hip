@@ -15,6 +15,7 @@
 //            is 64-bit fixed point (product in exact fp64, scaled by 2^shift, rounded to nearest
 //            even, added with an integer LDS atomic), so the sum does not depend on the order in
 //            which the waves arrive: results are bit-reproducible and a CPU checker can restate them.
+//            col_scale is folded into the stored values at set time (one fp32 rounding per entry).
 //
 // Both end in the same epilogue: column scale, exclusion bitmap in LDS, block-wide top-K of the
 // chunk (score descending, item index ascending), partial lists merged by merge_topk_kernel.
@@ -165,7 +166,12 @@ __global__ __launch_bounds__(II_BLOCK, 3) void item_item_kernel(ItemItemParams p
         for (int q = 0; q < PASSES; ++q) {
             if (q < npass) {
                 const f32x4 w = *reinterpret_cast<const f32x4 *>(p.pen + col0 + q * II_PASS);
-                acc[q][0] *= w[0]; acc[q][1] *= w[1]; acc[q][2] *= w[2]; acc[q][3] *= w[3];
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    // CSR values carry col_scale already; only an exact zero still meets it (0 * inf = NaN)
+                    if (SPARSE) acc[q][v] = acc[q][v] == 0.0f ? acc[q][v] * w[v] : acc[q][v];
+                    else acc[q][v] *= w[v];
+                }
             }
         }
     }
@@ -258,26 +264,38 @@ __global__ __launch_bounds__(II_BLOCK, 3) void item_item_kernel(ItemItemParams p
 }
 
 // ------------------------------------------------------------------------------------
-// CSR M, top-K: one workgroup per user sweeps the item chunks with ONE running top-K list.
-// Per chunk the work is proportional to the nonzeros that fall into it, not to the chunk:
-//   accumulate : 16-lane groups walk the chunk's segment of each history row; 64-bit fixed-point
-//                LDS atomics as above; the first touch of a column (atomicOr on a bitmap) appends
-//                it to a touched list;
-//   drain      : only touched columns are converted, scaled, tested against the current K-th
-//                best key and, if they pass, looked up in the exclusion row (LDS copy, binary
-//                search); their accumulators are reset on the way, so the 32 KB are zeroed once;
-//   merge      : qualifiers and the current list are ranked by counting (keys are unique:
-//                (orderable score, ~item) packed in 64 bits, larger = better);
-//   zeros      : untouched columns score exactly 0 * col_scale.  They can only matter while the
-//                list is not full or its K-th key is not above the chunk's best possible zero,
-//                and then only the K lowest item ids among them: a block prefix count picks those.
-// The end of a row's chunk segment is the start of its next one, so each (history row, chunk)
-// costs one pointer load, issued one chunk ahead.
+// CSR M, top-K: one workgroup per user with ONE running top-K list.  The user's catalogue is
+// swept in PASSES of consecutive item chunks; a pass takes as many chunks as hold at most
+// `sp_cap` (entry, exclusion) pairs of this user, found from the per-chunk entry positions
+// (cptr) summed over the history rows.  A typical user (a few thousand nonzeros in all its
+// history rows) is done in one to four passes instead of one per 4096-column chunk.
+//   plan       : Tc[c] = entries of all history rows + exclusions with column < c * 4096;
+//   hash pass  : the pass's entries are summed in an LDS hash table (open addressing, key =
+//                column + 1, 64-bit fixed-point value as above; the user's exclusions are
+//                entered first with a flag bit, entries that find a flagged key are dropped);
+//   dense pass : a single chunk with more than sp_cap entries falls back to 4096 direct-mapped
+//                64-bit accumulators + a touched bitmap in the same LDS;
+//   select     : every thread converts its table slots to (orderable score, ~item) keys in
+//                registers.  While the list is not full a lower bound of the K-th best comes from
+//                K rounds of a DPP wave maximum over the threads' best keys; keys above the bound
+//                (or above the list's K-th key) are appended behind a copy of the list and ranked
+//                by counting (keys are unique, larger = better);
+//   zeros      : columns no history row touches score exactly 0 * col_scale.  They only matter
+//                when the list ends up short or holds scores <= 0; only then a second sweep marks
+//                the touched columns per chunk and takes the K lowest untouched item ids.
 // ------------------------------------------------------------------------------------
-constexpr int SP_CHUNK = II_SPARSE_PASSES * II_PASS;   // 4096 columns, 32 KB of accumulators
-constexpr int SP_HIST = 256;                            // history rows staged per round
-constexpr int SP_SLAB = II_BLOCK;                       // touched columns drained per merge
-constexpr int SP_EXCAP = 512;                           // exclusion row entries kept in LDS
+constexpr int SP_CHUNK = II_SPARSE_PASSES * II_PASS;   // 4096 columns: granularity of cptr
+constexpr int SP_SPT = 14;                              // hash slots per thread
+constexpr int SP_SLOTS = II_BLOCK * SP_SPT;             // 3584 slots
+constexpr int SP_CAP = SP_SLOTS / 2;                    // entries per hash pass (load <= 0.5)
+constexpr int SP_RAW = SP_SLOTS * 3 / 2;                // 64-bit words: values, then 32-bit keys
+constexpr int SP_REG = SP_SPT > SP_CHUNK / II_BLOCK ? SP_SPT : SP_CHUNK / II_BLOCK;
+constexpr int SP_HIST = 128;                            // history rows staged per round
+constexpr int SP_EXCAP = 256;                           // exclusion row entries kept in LDS
+constexpr int SP_MAXCH = 512;                           // item chunks (catalogue <= 2 097 152 items)
+constexpr int SP_NG = II_BLOCK / II_GROUP;              // 16-lane groups per workgroup
+constexpr uint32_t SP_FLAG = 0x80000000u;               // key flag: excluded column
+static_assert(SP_RAW >= SP_CHUNK + 2 * (SP_CHUNK / 64) + 64, "dense pass accumulators + bitmaps must fit the table");
 
 __device__ __forceinline__ uint32_t sp_float_key(float x)
 {
@@ -292,21 +310,50 @@ __device__ __forceinline__ unsigned long long sp_key(float s, int col)
 {
     return ((unsigned long long)sp_float_key(s) << 32) | (uint32_t)(~col);
 }
+__device__ __forceinline__ int sp_slot(int col)
+{
+    return (int)(((((uint32_t)col * 0x9E3779B1u) >> 16) * (uint32_t)SP_SLOTS) >> 16);
+}
+// maximum over the 64 lanes (DPP row shifts + row broadcasts), returned to every lane
+__device__ __forceinline__ uint32_t sp_wave_max(uint32_t v)
+{
+#define SP_DPP_MAX(ctrl) v = max(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, ctrl, 0xf, 0xf, false))
+    SP_DPP_MAX(0x111);   // row_shr:1
+    SP_DPP_MAX(0x112);   // row_shr:2
+    SP_DPP_MAX(0x114);   // row_shr:4
+    SP_DPP_MAX(0x118);   // row_shr:8   -> lane 15 of each row holds the row maximum
+    SP_DPP_MAX(0x142);   // row_bcast:15
+    SP_DPP_MAX(0x143);   // row_bcast:31 -> lane 63 holds the wave maximum
+#undef SP_DPP_MAX
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+// sum over each row of 16 lanes, valid in the row's last lane
+__device__ __forceinline__ int sp_row_sum(int v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);
+    return v;
+}
 
 __global__ __launch_bounds__(II_BLOCK, 3) void item_sparse_topk_kernel(ItemItemParams p, int32_t *out_ids,
                                                                        float *out_scores)
 {
-    __shared__ unsigned long long acc64[SP_CHUNK];
-    __shared__ uint32_t tbm[SP_CHUNK / 32];
-    __shared__ uint16_t tlist[SP_CHUNK];
+    __shared__ unsigned long long raw[SP_RAW];          // hash table / dense accumulators / merge keys
+    __shared__ unsigned long long Tc[SP_MAXCH + 1];
     __shared__ int hj[SP_HIST];
     __shared__ float hx[SP_HIST];
-    __shared__ int64_t s0[SP_HIST], s1[SP_HIST];        // current chunk's segment of each staged row
+    __shared__ int64_t s0[SP_HIST], s1[SP_HIST];        // current pass's segment of each staged row
     __shared__ int exl[SP_EXCAP];
-    __shared__ unsigned long long qkey[SP_SLAB + 32];
     __shared__ unsigned long long top[32];
-    __shared__ int s_ntouch, s_nq, s_cnt;
-    __shared__ int wsum[II_BLOCK / 64];
+    __shared__ uint32_t wred[II_BLOCK / 64];
+    __shared__ int s_nq, s_cnt;
+    unsigned long long *const vals = raw;                                    // [SP_SLOTS]
+    uint32_t *const keys = reinterpret_cast<uint32_t *>(raw + SP_SLOTS);     // [SP_SLOTS]
+    unsigned long long *const qkey = raw;                                    // merge keys (table is in registers by then)
+    uint32_t *const tbm = reinterpret_cast<uint32_t *>(raw + SP_RAW - 2 * (SP_CHUNK / 64));   // touched columns of a chunk
+    uint32_t *const xbm = tbm + SP_CHUNK / 32;                                                // excluded columns of a chunk
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -319,191 +366,341 @@ __global__ __launch_bounds__(II_BLOCK, 3) void item_sparse_topk_kernel(ItemItemP
     int64_t hb = 0, he = 0, eb = 0, ee = 0;
     if (u >= 0 && u < p.h_rows) { hb = p.h_ptr[u]; he = p.h_ptr[u + 1]; }
     if (p.ex_ptr != nullptr && u >= 0 && u < p.ex_rows) { eb = p.ex_ptr[u]; ee = p.ex_ptr[u + 1]; }
-    const int n_ex = (int)(ee - eb);
+    const int64_t n_ex = ee - eb;
     const bool ex_lds = n_ex <= SP_EXCAP;
     const bool single = (he - hb) <= SP_HIST;           // the whole history fits one staging round
-
-    for (int w = tid; w < SP_CHUNK; w += II_BLOCK) acc64[w] = 0ull;
-    for (int w = tid; w < SP_CHUNK / 32; w += II_BLOCK) tbm[w] = 0u;
-    if (ex_lds) for (int w = tid; w < n_ex; w += II_BLOCK) exl[w] = p.ex_idx[eb + w];
-    if (tid < 32) top[tid] = 0ull;
-    if (tid == 0) { s_ntouch = 0; s_nq = 0; s_cnt = 0; }
-    if (single) {
-        const int m = (int)(he - hb);
-        for (int e = tid; e < m; e += II_BLOCK) {
-            const int j = p.h_idx[hb + e];
-            hj[e] = j;
-            hx[e] = p.h_val[hb + e];
-            const int64_t *cp = p.cptr + (int64_t)j * nc1;
-            s0[e] = cp[0];
-            s1[e] = cp[1];
-        }
-    }
-    __syncthreads();
-
-    auto excluded = [&](int col) -> bool {
-        int lo = 0, hi = n_ex;
-        if (ex_lds) {
-            while (lo < hi) { const int mid = (lo + hi) >> 1; if (exl[mid] < col) lo = mid + 1; else hi = mid; }
-            return lo < n_ex && exl[lo] == col;
-        }
-        while (lo < hi) { const int mid = (lo + hi) >> 1; if (p.ex_idx[eb + mid] < col) lo = mid + 1; else hi = mid; }
-        return lo < n_ex && p.ex_idx[eb + lo] == col;
-    };
-    // qualifiers in qkey[0, s_nq) + the current list -> the new list (block-uniform control flow)
-    auto merge = [&]() {
-        const int nq = s_nq;
-        if (nq == 0) return;
-        const int cnt = s_cnt;
-        if (tid < cnt) qkey[nq + tid] = top[tid];
-        __syncthreads();
-        const int total = nq + cnt;
-        for (int e = tid; e < total; e += II_BLOCK) {
-            const unsigned long long k = qkey[e];
-            int rank = 0;
-            for (int x = 0; x < total; ++x) rank += qkey[x] > k ? 1 : 0;
-            if (rank < K) top[rank] = k;
-        }
-        __syncthreads();
-        if (tid == 0) { s_cnt = min(K, total); s_nq = 0; }
-        __syncthreads();
-    };
-
-    // In single mode the first 16 entries of the NEXT chunk's segment of up to two rows per lane
-    // group are loaded one chunk ahead (pf_*), so a typical user (<= 32 history rows, segments of
-    // <= 16 entries) never waits on HBM inside the chunk loop.  A prefetch may read past its
-    // segment (never past the array); such entries are dropped by the q < q1 test at use.
-    int pf_i[2] = {0, 0};
-    float pf_v[2] = {0.f, 0.f};
     const int m1 = single ? (int)(he - hb) : 0;
-    auto prefetch = [&](int (&ri)[2], float (&rv)[2], const int64_t *start) {
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const int e = g + t * (II_BLOCK / II_GROUP);
-            if (e < m1) {
-                const int64_t q = start[e] + l;
-                if (q < p.m_nnz) { ri[t] = p.m_idx[q]; rv[t] = p.m_val[q]; }
+
+    for (int w = tid; w < SP_RAW; w += II_BLOCK) raw[w] = 0ull;
+    for (int w = tid; w < nc1; w += II_BLOCK) Tc[w] = 0ull;
+    if (ex_lds) for (int w = tid; w < (int)n_ex; w += II_BLOCK) exl[w] = p.ex_idx[eb + w];
+    if (tid < 32) top[tid] = 0ull;
+    if (tid == 0) { s_nq = 0; s_cnt = 0; }
+
+    // first exclusion entry with column >= col (every thread searches; block-uniform for uniform col)
+    auto ex_lower_bound = [&](int col) -> int64_t {
+        int64_t lo = 0, hi = n_ex;
+        if (ex_lds) { while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (exl[mid] < col) lo = mid + 1; else hi = mid; } }
+        else { while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (p.ex_idx[eb + mid] < col) lo = mid + 1; else hi = mid; } }
+        return lo;
+    };
+    auto excluded = [&](int col) -> bool {
+        const int64_t lo = ex_lower_bound(col);
+        return lo < n_ex && (ex_lds ? exl[lo] : p.ex_idx[eb + lo]) == col;
+    };
+    // fn(col) for the user's exclusions with colA <= col < colB
+    auto for_exclusions = [&](int colA, int colB, auto &&fn) {
+        if (n_ex == 0) return;
+        if (ex_lds) {
+            for (int w = tid; w < (int)n_ex; w += II_BLOCK) { const int c = exl[w]; if (c >= colA && c < colB) fn(c); }
+        } else {
+            for (int64_t w = ex_lower_bound(colA) + tid; w < n_ex; w += II_BLOCK) {
+                const int c = p.ex_idx[eb + w];
+                if (c >= colB) break;
+                fn(c);
             }
         }
     };
-    if (single) prefetch(pf_i, pf_v, s0);
-
-    for (int chunk = 0; chunk < p.n_chunks; ++chunk) {
-        const int c0 = chunk * SP_CHUNK;
-        auto apply = [&](int ci, float wv, double x) {
-            const int c = ci - c0;
-            const double pr = x * (double)wv;                                  // exact: 24 x 24 bits
-            const long long v = __double2ll_rn(ldexp(pr, p.fx_shift));          // nearest even
-            atomicAdd(&acc64[c], (unsigned long long)v);
-            const uint32_t bit = 1u << (c & 31);
-            if (!(atomicOr(&tbm[c >> 5], bit) & bit)) tlist[atomicAdd(&s_ntouch, 1)] = (uint16_t)c;
-        };
-        // ---- accumulate
-        if (single) {
-            const int m = m1;
-            int nf_i[2] = {0, 0};
-            float nf_v[2] = {0.f, 0.f};
-            int64_t nxt = 0;
-            if (chunk + 1 < p.n_chunks) {
-                prefetch(nf_i, nf_v, s1);
-                // the boundary after the NEXT chunk, in flight while this chunk is accumulated
-                if (tid < m) nxt = p.cptr[(int64_t)hj[tid] * nc1 + chunk + 2];
-            }
+    // rows [base, base + m) of the history: item, weight and the entry range of chunks [ca, cb)
+    auto stage = [&](int64_t base, int m, int ca, int cb, bool load_rows) {
+        for (int e = tid; e < m; e += II_BLOCK) {
+            int j;
+            if (load_rows) { j = p.h_idx[base + e]; hj[e] = j; hx[e] = p.h_val[base + e]; }
+            else j = hj[e];
+            const int64_t *cp = p.cptr + (int64_t)j * nc1;
+            s0[e] = cp[ca];
+            s1[e] = cp[cb];
+        }
+    };
+    // fn(cols[4], vals[4], ok[4], x) over the staged rows' segments: a 16-lane group per row, four
+    // strides of 16 entries in flight per lane
+    auto sweep = [&](int m, auto &&fn) {
+        const int gpr = m > 0 && m < SP_NG ? SP_NG / m : 1;     // lane groups per row (short histories)
+        const int step = 4 * II_GROUP * gpr;
+        for (int e = g / gpr; e < m; e += SP_NG / gpr) {
+            if (gpr > 1 && g >= gpr * m) break;                   // groups left over
+            const double x = ldexp((double)hx[e], p.fx_shift);
+            const int64_t q1 = s1[e];
+            int64_t q = s0[e] + (g % gpr) * (4 * II_GROUP) + l;
+            int c[4], cn[4];
+            float w[4], wn[4];
+            auto load = [&](int64_t qb, int (&ci)[4], float (&wi)[4]) {
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const int e = g + t * (II_BLOCK / II_GROUP);
-                if (e < m) {
-                    const double x = (double)hx[e];
-                    const int64_t q1 = s1[e];
-                    int64_t q = s0[e] + l;
-                    if (q < q1) apply(pf_i[t], pf_v[t], x);
-                    for (q += II_GROUP; q < q1; q += II_GROUP) apply(p.m_idx[q], p.m_val[q], x);
+                for (int t = 0; t < 4; ++t) {
+                    const int64_t qq = qb + t * II_GROUP;
+                    const int64_t qc = qq < q1 ? qq : q1 - 1;
+                    ci[t] = p.m_idx[qc];
+                    wi[t] = p.m_val[qc];
                 }
+            };
+            if (q < q1) load(q, c, w);
+            while (q < q1) {
+                const int64_t qn = q + step;
+                if (qn < q1) load(qn, cn, wn);
+                bool ok[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) ok[t] = q + t * II_GROUP < q1;
+                fn(c, w, ok, x);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) { c[t] = cn[t]; w[t] = wn[t]; }
+                q = qn;
             }
-            for (int e = g + 2 * (II_BLOCK / II_GROUP); e < m; e += II_BLOCK / II_GROUP) {
-                const double x = (double)hx[e];
-                const int64_t q1 = s1[e];
-                for (int64_t q = s0[e] + l; q < q1; q += II_GROUP) apply(p.m_idx[q], p.m_val[q], x);
-            }
+        }
+    };
+    // every entry of the user's history rows with column in chunks [ca, cb); `pre` runs before the
+    // first barrier (table set-up that the accumulation must see)
+    auto walk = [&](int ca, int cb, auto &&fn) {
+        if (single) {
+            stage(hb, m1, ca, cb, false);
             __syncthreads();
-            if (tid < m) { s0[tid] = s1[tid]; s1[tid] = nxt; }
-            pf_i[0] = nf_i[0]; pf_i[1] = nf_i[1]; pf_v[0] = nf_v[0]; pf_v[1] = nf_v[1];
+            sweep(m1, fn);
         } else {
             for (int64_t base = hb; base < he; base += SP_HIST) {
                 const int m = (int)min((int64_t)SP_HIST, he - base);
                 __syncthreads();
-                for (int e = tid; e < m; e += II_BLOCK) {
-                    const int j = p.h_idx[base + e];
-                    hj[e] = j;
-                    hx[e] = p.h_val[base + e];
-                    const int64_t *cp = p.cptr + (int64_t)j * nc1 + chunk;
-                    s0[e] = cp[0];
-                    s1[e] = cp[1];
-                }
+                stage(base, m, ca, cb, true);
                 __syncthreads();
-                for (int e = g; e < m; e += II_BLOCK / II_GROUP) {
-                    const double x = (double)hx[e];
-                    const int64_t q1 = s1[e];
-                    for (int64_t q = s0[e] + l; q < q1; q += II_GROUP) apply(p.m_idx[q], p.m_val[q], x);
-                }
+                sweep(m, fn);
+            }
+        }
+    };
+    // x = history weight * 2^shift (exact); the product is exact (24 x 24 bits), rounded to nearest even
+    auto fixed = [&](float wv, double x) -> unsigned long long {
+        return (unsigned long long)__double2ll_rn(x * (double)wv);
+    };
+    // qkey[0, cnt) = the list, qkey[cnt, s_nq) = new keys -> the new list; call after a barrier
+    auto rank_merge = [&]() {
+        const int total = s_nq, cnt = s_cnt;
+        if (total > cnt) {
+            for (int e0 = 0; e0 < total; e0 += SP_NG) {
+                const int e = e0 + g;
+                const unsigned long long k = e < total ? qkey[e] : ~0ull;
+                int r = 0;
+                for (int x = l; x < total; x += II_GROUP) r += qkey[x] > k ? 1 : 0;
+                r = sp_row_sum(r);
+                if (l == II_GROUP - 1 && e < total && r < K) top[r] = k;
             }
         }
         __syncthreads();
-        // ---- drain the touched columns, one slab per merge
-        const int nt = s_ntouch;
-        for (int sbase = 0; sbase < nt; sbase += SP_SLAB) {
-            const int cnt = s_cnt;
-            const unsigned long long tau = cnt == K ? top[K - 1] : 0ull;
-            const int e = sbase + tid;
-            if (e < nt) {
-                const int lc = tlist[e];
-                const long long a = (long long)acc64[lc];
-                acc64[lc] = 0ull;
-                const int col = c0 + lc;
-                float s = (float)ldexp((double)a, -p.fx_shift);
-                if (p.pen != nullptr) s *= p.pen[col];
-                if (s == s) {
-                    if (s == 0.0f) s = 0.0f;                                   // -0 ranks as +0
-                    const unsigned long long k = sp_key(s, col);
-                    if (k > tau && !excluded(col)) qkey[atomicAdd(&s_nq, 1)] = k;
-                }
-            }
-            __syncthreads();
-            merge();
+        for (int e = tid; e < total; e += II_BLOCK) qkey[e] = 0ull;
+        if (tid == 0) { const int c = min(K, total); s_cnt = c; s_nq = c; }
+        if (total > SP_SLOTS) __syncthreads();                                  // zeroed words reach into the key area
+    };
+
+    // ---- plan: Tc[c] = entries + exclusions below the start of chunk c
+    __syncthreads();
+    for (int64_t base = hb; base < he; base += SP_HIST) {
+        const int m = (int)min((int64_t)SP_HIST, he - base);
+        if (base != hb) __syncthreads();
+        for (int e = tid; e < m; e += II_BLOCK) { hj[e] = p.h_idx[base + e]; hx[e] = p.h_val[base + e]; }
+        __syncthreads();
+        for (int e = g; e < m; e += SP_NG) {
+            const int64_t *cp = p.cptr + (int64_t)hj[e] * nc1;
+            const int64_t r0 = cp[0];
+            for (int c = l + 1; c < nc1; c += II_GROUP) atomicAdd(&Tc[c], (unsigned long long)(cp[c] - r0));
         }
-        // ---- untouched columns (score 0 * col_scale), only while they can still enter the list
-        {
-            const int cnt = s_cnt;
-            const unsigned long long tau = cnt == K ? top[K - 1] : 0ull;
-            if (cnt < K || sp_key(0.0f, c0) > tau) {
-                int mine = 0;
-                uint32_t okbits = 0;
-#pragma unroll 4
-                for (int v = 0; v < 16; ++v) {
-                    const int lc = 16 * tid + v;
-                    const int col = c0 + lc;
-                    bool ok = col < p.n_items && !((tbm[lc >> 5] >> (lc & 31)) & 1u);
-                    if (ok && p.pen != nullptr) { const float z = 0.0f * p.pen[col]; ok = z == z; }
-                    if (ok) ok = sp_key(0.0f, col) > tau && !excluded(col);
-                    if (ok) { okbits |= 1u << v; ++mine; }
+    }
+    if (n_ex > 0) {
+        __syncthreads();
+        for (int c = tid + 1; c < nc1; c += II_BLOCK)
+            Tc[c] += (unsigned long long)ex_lower_bound(c >= (1 << 30) / SP_CHUNK ? 0x7fffffff : c * SP_CHUNK);
+    }
+    __syncthreads();
+
+    // equal shares: ceil(total / cap) passes of about total / passes entries keep the table load even
+    unsigned long long cap = (unsigned long long)p.sp_cap;
+    {
+        const unsigned long long total = Tc[p.n_chunks], np = (total + cap - 1) / cap;
+        if (np > 1) cap = min(cap, (total + np - 1) / np + cap / 8);
+    }
+    int ca = 0;
+    while (ca < p.n_chunks) {
+        // ---- the pass: chunks [ca, cb)
+        const unsigned long long t0 = Tc[ca];
+        int cb = ca;
+        for (;;) {
+            const int ci = cb + 1 + lane;
+            const bool fits = ci <= p.n_chunks && Tc[min(ci, p.n_chunks)] - t0 <= cap;
+            const int n = __builtin_amdgcn_readfirstlane(__popcll(__ballot(fits)));   // Tc ascends: a prefix of lanes
+            cb += n;
+            if (n < 64) break;
+        }
+        const bool dense = cb == ca;
+        if (dense) cb = ca + 1;
+        if (Tc[cb] == t0) { ca = cb; continue; }          // nothing of this user in these chunks
+        const int colA = ca * SP_CHUNK;
+        const int colB = cb >= (1 << 30) / SP_CHUNK ? 0x7fffffff : cb * SP_CHUNK;
+
+        unsigned long long kreg[SP_REG];
+        if (!dense) {
+            for_exclusions(colA, colB, [&](int col) {
+                const uint32_t key = (uint32_t)(col + 1);
+                int slot = sp_slot(col);
+                for (;;) {
+                    const uint32_t old = atomicCAS(&keys[slot], 0u, key | SP_FLAG);
+                    if (old == 0u || (old & ~SP_FLAG) == key) break;
+                    slot = slot + 1 == SP_SLOTS ? 0 : slot + 1;
                 }
-                int incl = mine;                                              // block exclusive prefix of `mine`
+            });
+            walk(ca, cb, [&](const int (&c)[4], const float (&w)[4], const bool (&ok)[4], double x) {
+                // every round probes all four entries (finished ones with key 0: CAS(0 -> 0) changes nothing)
+                uint32_t key[4];
+                int slot[4];
+                unsigned long long val[4];
 #pragma unroll
-                for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(incl, off); if (lane >= off) incl += t; }
-                if (lane == 63) wsum[wave] = incl;
-                __syncthreads();
-                int before = incl - mine;
-                for (int w = 0; w < wave; ++w) before += wsum[w];
-                for (int v = 0; v < 16 && before < K; ++v)
-                    if (okbits & (1u << v)) { qkey[atomicAdd(&s_nq, 1)] = sp_key(0.0f, c0 + 16 * tid + v); ++before; }
-                __syncthreads();
-                merge();
+                for (int t = 0; t < 4; ++t) {
+                    key[t] = ok[t] ? (uint32_t)(c[t] + 1) : 0u;
+                    slot[t] = sp_slot(c[t]);
+                    val[t] = fixed(w[t], x);
+                }
+                for (int round = 0;; ++round) {
+                    uint32_t old[4];
+                    if (round == 0) {
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) old[t] = atomicCAS(&keys[slot[t]], 0u, key[t]);
+                    } else {
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) { old[t] = 0u; if (key[t] != 0u) old[t] = atomicCAS(&keys[slot[t]], 0u, key[t]); }
+                    }
+                    bool more = false;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const bool hit = key[t] == 0u || old[t] == 0u || (old[t] & ~SP_FLAG) == key[t];
+                        if (hit && key[t] != 0u && !(old[t] & SP_FLAG)) atomicAdd(&vals[slot[t]], val[t]);
+                        key[t] = hit ? 0u : key[t];
+                        const int nx = slot[t] + 1 == SP_SLOTS ? 0 : slot[t] + 1;
+                        slot[t] = hit ? slot[t] : nx;
+                        more |= !hit;
+                    }
+                    if (!__any(more)) break;
+                }
+            });
+            __syncthreads();
+            // ---- table slots -> sort keys in registers; the slots are left empty
+            uint32_t kk[SP_SPT];
+            unsigned long long av[SP_SPT];
+#pragma unroll
+            for (int v = 0; v < SP_SPT; ++v) { kk[v] = keys[tid + v * II_BLOCK]; av[v] = vals[tid + v * II_BLOCK]; }
+#pragma unroll
+            for (int v = 0; v < SP_SPT; ++v) { keys[tid + v * II_BLOCK] = 0u; vals[tid + v * II_BLOCK] = 0ull; }
+#pragma unroll
+            for (int v = 0; v < SP_REG; ++v) {
+                kreg[v] = 0ull;
+                if (v >= SP_SPT) continue;
+                const int col = (int)((kk[v] & ~SP_FLAG) - 1u);
+                float s = (float)ldexp((double)(long long)av[v], -p.fx_shift);  // col_scale is folded into the values
+                const bool live = kk[v] != 0u && !(kk[v] & SP_FLAG);
+                if (live && s == 0.0f && p.pen != nullptr) s *= p.pen[col];     // 0 * inf = NaN like the reference
+                if (s == 0.0f) s = 0.0f;                                        // -0 ranks as +0
+                kreg[v] = live && s == s ? sp_key(s, col) : 0ull;
+            }
+        } else {
+            for_exclusions(colA, colB, [&](int col) { atomicOr(&xbm[(col - colA) >> 5], 1u << (col & 31)); });
+            walk(ca, cb, [&](const int (&c)[4], const float (&w)[4], const bool (&ok)[4], double x) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {                                   // a clamped duplicate adds 0 / ors 0
+                    const int lc = c[t] - colA;
+                    atomicAdd(&raw[lc], ok[t] ? fixed(w[t], x) : 0ull);
+                    atomicOr(&tbm[lc >> 5], ok[t] ? 1u << (lc & 31) : 0u);
+                }
+            });
+            __syncthreads();
+#pragma unroll
+            for (int v = 0; v < SP_REG; ++v) {
+                kreg[v] = 0ull;
+                if (v >= SP_CHUNK / II_BLOCK) continue;
+                const int lc = tid + v * II_BLOCK;
+                const uint32_t bit = 1u << (lc & 31);
+                if (!(tbm[lc >> 5] & bit)) continue;
+                const long long a = (long long)raw[lc];
+                raw[lc] = 0ull;
+                if (xbm[lc >> 5] & bit) continue;
+                const int col = colA + lc;
+                float s = (float)ldexp((double)a, -p.fx_shift);
+                if (s == 0.0f && p.pen != nullptr) s *= p.pen[col];
+                if (s != s) continue;
+                if (s == 0.0f) s = 0.0f;
+                kreg[v] = sp_key(s, col);
             }
         }
-        // ---- reset the touched bitmap and list for the next chunk
-        for (int w = tid; w < SP_CHUNK / 32; w += II_BLOCK) tbm[w] = 0u;
-        if (tid == 0) s_ntouch = 0;
+        // ---- bound: the list's K-th key, or (list not full) the best wave's K-th best thread maximum
+        const int cnt = s_cnt;
+        if (cnt < K) {
+            uint32_t lm = 0u;
+#pragma unroll
+            for (int v = 0; v < SP_REG; ++v) lm = max(lm, (uint32_t)(kreg[v] >> 32));
+            uint32_t vk = 0u;
+            for (int r = 0; r < K; ++r) {
+                vk = sp_wave_max(lm);
+                if (vk == 0u) break;
+                const unsigned long long b = __ballot(lm == vk);
+                if (lane == __ffsll((long long)b) - 1) lm = 0u;
+            }
+            if (lane == 0) wred[wave] = vk;
+        }
+        __syncthreads();                                   // every slot is in registers: raw becomes qkey
+        unsigned long long tau;
+        if (cnt < K) {
+            uint32_t th = 0u;
+#pragma unroll
+            for (int w = 0; w < II_BLOCK / 64; ++w) th = max(th, wred[w]);
+            tau = th ? ((unsigned long long)th << 32) - 1ull : 0ull;
+        } else tau = top[K - 1];
+        if (dense && tid < 2 * (SP_CHUNK / 32)) tbm[tid] = 0u;                  // tbm and xbm are contiguous
+        if (tid < cnt) qkey[tid] = top[tid];
+#pragma unroll
+        for (int v = 0; v < SP_REG; ++v) {
+            const bool q = kreg[v] > tau;
+            if (__any(q)) { if (q) qkey[atomicAdd(&s_nq, 1)] = kreg[v]; }
+        }
         __syncthreads();
+        rank_merge();
+        ca = cb;
+    }
+    __syncthreads();
+
+    // ---- untouched columns (score 0 * col_scale): only when they can still enter the list
+    {
+        uint32_t *const zbm = reinterpret_cast<uint32_t *>(raw + SP_RAW - SP_CHUNK / 64);
+        int found = 0;
+        for (int chunk = 0; chunk < p.n_chunks && found < K; ++chunk) {
+            const int c0 = chunk * SP_CHUNK;
+            const int cnt = s_cnt;
+            const unsigned long long tau = cnt == K ? top[K - 1] : 0ull;
+            if (cnt == K && !(sp_key(0.0f, c0) > tau)) break;
+            walk(chunk, chunk + 1, [&](const int (&c)[4], const float (&)[4], const bool (&ok)[4], double) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    if (ok[t]) { const int lc = c[t] - c0; atomicOr(&zbm[lc >> 5], 1u << (lc & 31)); }
+            });
+            __syncthreads();
+            int mine = 0;
+            uint32_t okbits = 0;
+            for (int v = 0; v < 16; ++v) {
+                const int lc = 16 * tid + v;
+                const int col = c0 + lc;
+                bool ok = col < p.n_items && !((zbm[lc >> 5] >> (lc & 31)) & 1u);
+                if (ok && p.pen != nullptr) { const float z = 0.0f * p.pen[col]; ok = z == z; }
+                if (ok) ok = sp_key(0.0f, col) > tau && !excluded(col);
+                if (ok) { okbits |= 1u << v; ++mine; }
+            }
+            int incl = mine;                                                  // block exclusive prefix of `mine`
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(incl, off); if (lane >= off) incl += t; }
+            if (lane == 63) wred[wave] = (uint32_t)incl;
+            __syncthreads();
+            int before = incl - mine, all = 0;
+            for (int w = 0; w < II_BLOCK / 64; ++w) { if (w < wave) before += (int)wred[w]; all += (int)wred[w]; }
+            if (tid < SP_CHUNK / 32) zbm[tid] = 0u;
+            if (tid < cnt) qkey[tid] = top[tid];
+            before += found;
+            for (int v = 0; v < 16 && before < K; ++v)
+                if (okbits & (1u << v)) { qkey[atomicAdd(&s_nq, 1)] = sp_key(0.0f, c0 + 16 * tid + v); ++before; }
+            found += all;
+            __syncthreads();
+            rank_merge();
+            __syncthreads();
+        }
     }
 
     const int cnt = s_cnt;
@@ -517,9 +714,12 @@ __global__ __launch_bounds__(II_BLOCK, 3) void item_sparse_topk_kernel(ItemItemP
 int launch_item_sparse_topk(const ItemItemParams &p, int32_t *out_ids, float *out_scores, hipStream_t stream)
 {
     if (p.n <= 0 || p.n > (int64_t)0xffffffffu / II_BLOCK || p.K < 1 || p.K > 32) return -1;
+    if (p.n_chunks < 1 || p.n_chunks > SP_MAXCH || p.sp_cap < 1 || p.sp_cap > SP_CAP) return -1;
     hipLaunchKernelGGL(item_sparse_topk_kernel, dim3((unsigned)p.n), dim3(II_BLOCK), 0, stream, p, out_ids, out_scores);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
+int item_sparse_pass_capacity() { return SP_CAP; }
+int item_sparse_max_chunks() { return SP_MAXCH; }
 
 int launch_item_item(const ItemItemParams &p, bool sparse, bool topk, hipStream_t stream)
 {
@@ -570,6 +770,21 @@ __global__ void build_chunk_ptr_kernel(const int64_t *ptr, const int32_t *idx, i
     const int64_t target = (int64_t)c * chunk;
     while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (idx[mid] < target) lo = mid + 1; else hi = mid; }
     cptr[t] = lo;
+}
+
+// values[q] *= col_scale[column of q]: the column scale of a CSR item matrix is folded into its values
+__global__ void scale_csr_values_kernel(float *val, const int32_t *idx, int64_t nnz, const float *col_scale)
+{
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < nnz; q += (int64_t)gridDim.x * blockDim.x)
+        val[q] = val[q] * col_scale[idx[q]];
+}
+
+int launch_scale_csr_values(float *val, const int32_t *idx, int64_t nnz, const float *col_scale, hipStream_t s)
+{
+    const int64_t blocks = (nnz + 255) / 256;
+    const unsigned grid = (unsigned)(blocks < 1 ? 1 : (blocks > 8192 ? 8192 : blocks));
+    hipLaunchKernelGGL(scale_csr_values_kernel, dim3(grid), dim3(256), 0, s, val, idx, nnz, col_scale);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
 // max |x| as the bits of a non-negative float (NaN sorts above +inf and is caught by the host)

@@ -92,7 +92,36 @@ def test_csr_topk_bit_exact_vs_oracle(torch, n_items, row_nnz, K, pen):
     np.testing.assert_array_equal(ids.cpu().numpy(), o_ids)
     np.testing.assert_array_equal(scores.cpu().numpy(), o_sc)
     # the library's shift follows the documented rule
-    assert sc.item_fixed_point_shift() == orc.item_fixed_point_shift(w["csr"].data, w["h_ptr"], w["h_val"])
+    assert sc.item_fixed_point_shift() == orc.item_fixed_point_shift(w["csr"].data, w["h_ptr"], w["h_val"], w["csr"].indices,
+                                                                   w["col_scale"])
+
+
+@pytest.mark.parametrize("pass_entries", [0, 700, 40])
+def test_csr_topk_pass_shapes(torch, pass_entries):
+    """The CSR top-K kernel under every pass shape: one hash pass, many hash passes, single-chunk dense passes
+    (pass_entries below a chunk's entries), histories longer than a staging round (128 rows), exclusion rows beyond
+    the LDS copy (256 entries), negative values (zero-score columns enter the list) and users without history."""
+    w = _workload(77, 160, 9000, 120, row_nnz=60, weights="ratings", pen=True)
+    assert np.diff(w["h_ptr"]).max() > 256                                  # staging rounds and a global exclusion row
+    w["csr"].data[::3] *= -1.0
+    sc = _scorer(w)
+    if pass_entries:
+        sc.set_option("csr_pass_entries", pass_entries)
+    users = np.r_[np.arange(w["n_users"]), [w["n_users"] + 5]].astype(np.int32)
+    for K in (10, 32):
+        ids, scores = sc.rank_topk(users, K)
+        o_ids, o_sc, _, _ = _oracle(w, sc, users, [K], K)
+        np.testing.assert_array_equal(ids.cpu().numpy(), o_ids)
+        np.testing.assert_array_equal(scores.cpu().numpy(), o_sc)
+    # all-negative model: every touched column loses against the untouched (zero-score) ones
+    w["csr"].data[:] = -np.abs(w["csr"].data)
+    sc = _scorer(w)
+    if pass_entries:
+        sc.set_option("csr_pass_entries", pass_entries)
+    ids, scores = sc.rank_topk(users, 10)
+    o_ids, o_sc, _, _ = _oracle(w, sc, users, [10], 10)
+    np.testing.assert_array_equal(ids.cpu().numpy(), o_ids)
+    np.testing.assert_array_equal(scores.cpu().numpy(), o_sc)
 
 
 def test_csr_equals_dense_form_within_fp32_rounding(torch):

@@ -266,7 +266,7 @@ def test_item_restatements_against_reference_rp3(toy):
     A_bin = sp.csr_matrix((X > 0).astype(np.float64))
     P32, W32, pen = orc.rp3_model_arrays(A_bin, float(d["rp3_beta"]))
     Wd = W32.toarray()
-    shift = orc.item_fixed_point_shift(W32.data, P32.indptr, P32.data)
+    shift = orc.item_fixed_point_shift(W32.data, P32.indptr, P32.data, W32.indices, pen)
     assert 40 < shift < 80
     for u, ref in zip(d["rp3__score_users"], d["rp3__score_vecs"]):
         hi, hv = _hist(P32, int(u))

@@ -1,0 +1,20 @@
+"""Dev: time the CSR top-K kernel alone on the C5 workload (IFR_DEBUG_MODE ablations change results)."""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from recommenders_amd import HipScorer, synth
+nu = int(sys.argv[1]) if len(sys.argv) > 1 else 262144
+w = synth.make_item("c5_rp3_ebnerd", n_users=nu)
+sc = HipScorer(0)
+sc.set_item_matrix_csr(w["m_ptr"], w["m_idx"], w["m_val"], w["n_items"], w["col_scale"])
+sc.set_history_csr(w["h_ptr"], w["h_idx"], w["h_val"])
+sc.set_exclusion_csr(w["excl_ptr"], w["excl_idx"])
+users = np.arange(nu, dtype=np.int32)
+for dbg in [int(a) for a in (sys.argv[2].split(",") if len(sys.argv) > 2 else ["0"])]:
+    sc.set_option("debug_mode", dbg)
+    sc.rank_topk(users, 10); torch.cuda.synchronize()
+    t = time.perf_counter()
+    for _ in range(3): sc.rank_topk(users, 10)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t) / 3
+    print(f"dbg {dbg}: {dt*1e3:.2f} ms  {nu/dt/1e6:.2f} M users/s", flush=True)
