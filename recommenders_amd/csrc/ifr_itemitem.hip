@@ -285,15 +285,17 @@ __global__ __launch_bounds__(II_BLOCK, 3) void item_item_kernel(ItemItemParams p
 //                the touched columns per chunk and takes the K lowest untouched item ids.
 // ------------------------------------------------------------------------------------
 constexpr int SP_CHUNK = II_SPARSE_PASSES * II_PASS;   // 4096 columns: granularity of cptr
-constexpr int SP_SPT = 14;                              // hash slots per thread
-constexpr int SP_SLOTS = II_BLOCK * SP_SPT;             // 3584 slots
-constexpr int SP_CAP = SP_SLOTS / 2;                    // entries per hash pass (load <= 0.5)
+constexpr int SP_BLOCK = 512;                           // threads per user: two workgroups (4 waves/SIMD) per CU
+constexpr int SP_SPT = 11;                              // hash slots per thread
+constexpr int SP_SLOTS = SP_BLOCK * SP_SPT;             // 5632 slots
+constexpr int SP_CAP = SP_SLOTS * 5 / 8;                // entries per hash pass (load <= 0.625; flat optimum 0.5-0.65)
 constexpr int SP_RAW = SP_SLOTS * 3 / 2;                // 64-bit words: values, then 32-bit keys
-constexpr int SP_REG = SP_SPT > SP_CHUNK / II_BLOCK ? SP_SPT : SP_CHUNK / II_BLOCK;
+constexpr int SP_REG = SP_SPT > SP_CHUNK / SP_BLOCK ? SP_SPT : SP_CHUNK / SP_BLOCK;
 constexpr int SP_HIST = 128;                            // history rows staged per round
 constexpr int SP_EXCAP = 256;                           // exclusion row entries kept in LDS
 constexpr int SP_MAXCH = 512;                           // item chunks (catalogue <= 2 097 152 items)
-constexpr int SP_NG = II_BLOCK / II_GROUP;              // 16-lane groups per workgroup
+constexpr int SP_NG = SP_BLOCK / II_GROUP;
+constexpr int SP_ZC = SP_CHUNK / SP_BLOCK;               // columns per thread in the zero sweep              // 16-lane groups per workgroup
 constexpr uint32_t SP_FLAG = 0x80000000u;               // key flag: excluded column
 static_assert(SP_RAW >= SP_CHUNK + 2 * (SP_CHUNK / 64) + 64, "dense pass accumulators + bitmaps must fit the table");
 
@@ -337,18 +339,24 @@ __device__ __forceinline__ int sp_row_sum(int v)
     return v;
 }
 
-__global__ __launch_bounds__(II_BLOCK, 3) void item_sparse_topk_kernel(ItemItemParams p, int32_t *out_ids,
+constexpr size_t SP_LDS_BYTES = (size_t)SP_RAW * 8 + (SP_MAXCH + 1) * 8 + 2 * SP_HIST * 8 + 32 * 8 + 2 * SP_HIST * 4 +
+                                SP_EXCAP * 4 + (SP_BLOCK / 64) * 4 + 8;
+
+__global__ __launch_bounds__(SP_BLOCK, 4) void item_sparse_topk_kernel(ItemItemParams p, int32_t *out_ids,
                                                                        float *out_scores)
 {
-    __shared__ unsigned long long raw[SP_RAW];          // hash table / dense accumulators / merge keys
-    __shared__ unsigned long long Tc[SP_MAXCH + 1];
-    __shared__ int hj[SP_HIST];
-    __shared__ float hx[SP_HIST];
-    __shared__ int64_t s0[SP_HIST], s1[SP_HIST];        // current pass's segment of each staged row
-    __shared__ int exl[SP_EXCAP];
-    __shared__ unsigned long long top[32];
-    __shared__ uint32_t wred[II_BLOCK / 64];
-    __shared__ int s_nq, s_cnt;
+    extern __shared__ __attribute__((aligned(16))) unsigned char sp_lds[];   // > 64 KB: dynamic
+    unsigned long long *const raw = reinterpret_cast<unsigned long long *>(sp_lds);          // [SP_RAW] table / accumulators / merge keys
+    unsigned long long *const Tc = raw + SP_RAW;                                             // [SP_MAXCH + 1]
+    int64_t *const s0 = reinterpret_cast<int64_t *>(Tc + SP_MAXCH + 1);                      // [SP_HIST] current pass's segment
+    int64_t *const s1 = s0 + SP_HIST;                                                        // [SP_HIST]   of each staged row
+    unsigned long long *const top = reinterpret_cast<unsigned long long *>(s1 + SP_HIST);    // [32]
+    int *const hj = reinterpret_cast<int *>(top + 32);                                       // [SP_HIST]
+    float *const hx = reinterpret_cast<float *>(hj + SP_HIST);                               // [SP_HIST]
+    int *const exl = reinterpret_cast<int *>(hx + SP_HIST);                                  // [SP_EXCAP]
+    uint32_t *const wred = reinterpret_cast<uint32_t *>(exl + SP_EXCAP);                     // [SP_BLOCK / 64]
+    int &s_nq = *reinterpret_cast<int *>(wred + SP_BLOCK / 64);
+    int &s_cnt = *(&s_nq + 1);
     unsigned long long *const vals = raw;                                    // [SP_SLOTS]
     uint32_t *const keys = reinterpret_cast<uint32_t *>(raw + SP_SLOTS);     // [SP_SLOTS]
     unsigned long long *const qkey = raw;                                    // merge keys (table is in registers by then)
@@ -371,9 +379,9 @@ __global__ __launch_bounds__(II_BLOCK, 3) void item_sparse_topk_kernel(ItemItemP
     const bool single = (he - hb) <= SP_HIST;           // the whole history fits one staging round
     const int m1 = single ? (int)(he - hb) : 0;
 
-    for (int w = tid; w < SP_RAW; w += II_BLOCK) raw[w] = 0ull;
-    for (int w = tid; w < nc1; w += II_BLOCK) Tc[w] = 0ull;
-    if (ex_lds) for (int w = tid; w < (int)n_ex; w += II_BLOCK) exl[w] = p.ex_idx[eb + w];
+    for (int w = tid; w < SP_RAW; w += SP_BLOCK) raw[w] = 0ull;
+    for (int w = tid; w < nc1; w += SP_BLOCK) Tc[w] = 0ull;
+    if (ex_lds) for (int w = tid; w < (int)n_ex; w += SP_BLOCK) exl[w] = p.ex_idx[eb + w];
     if (tid < 32) top[tid] = 0ull;
     if (tid == 0) { s_nq = 0; s_cnt = 0; }
 
@@ -392,9 +400,9 @@ __global__ __launch_bounds__(II_BLOCK, 3) void item_sparse_topk_kernel(ItemItemP
     auto for_exclusions = [&](int colA, int colB, auto &&fn) {
         if (n_ex == 0) return;
         if (ex_lds) {
-            for (int w = tid; w < (int)n_ex; w += II_BLOCK) { const int c = exl[w]; if (c >= colA && c < colB) fn(c); }
+            for (int w = tid; w < (int)n_ex; w += SP_BLOCK) { const int c = exl[w]; if (c >= colA && c < colB) fn(c); }
         } else {
-            for (int64_t w = ex_lower_bound(colA) + tid; w < n_ex; w += II_BLOCK) {
+            for (int64_t w = ex_lower_bound(colA) + tid; w < n_ex; w += SP_BLOCK) {
                 const int c = p.ex_idx[eb + w];
                 if (c >= colB) break;
                 fn(c);
@@ -403,7 +411,7 @@ __global__ __launch_bounds__(II_BLOCK, 3) void item_sparse_topk_kernel(ItemItemP
     };
     // rows [base, base + m) of the history: item, weight and the entry range of chunks [ca, cb)
     auto stage = [&](int64_t base, int m, int ca, int cb, bool load_rows) {
-        for (int e = tid; e < m; e += II_BLOCK) {
+        for (int e = tid; e < m; e += SP_BLOCK) {
             int j;
             if (load_rows) { j = p.h_idx[base + e]; hj[e] = j; hx[e] = p.h_val[base + e]; }
             else j = hj[e];
@@ -471,7 +479,7 @@ __global__ __launch_bounds__(II_BLOCK, 3) void item_sparse_topk_kernel(ItemItemP
     // qkey[0, cnt) = the list, qkey[cnt, s_nq) = new keys -> the new list; call after a barrier
     auto rank_merge = [&]() {
         const int total = s_nq, cnt = s_cnt;
-        if (total > cnt) {
+        if (total > cnt && p.dbg != 105) {
             for (int e0 = 0; e0 < total; e0 += SP_NG) {
                 const int e = e0 + g;
                 const unsigned long long k = e < total ? qkey[e] : ~0ull;
@@ -482,7 +490,7 @@ __global__ __launch_bounds__(II_BLOCK, 3) void item_sparse_topk_kernel(ItemItemP
             }
         }
         __syncthreads();
-        for (int e = tid; e < total; e += II_BLOCK) qkey[e] = 0ull;
+        for (int e = tid; e < total; e += SP_BLOCK) qkey[e] = 0ull;
         if (tid == 0) { const int c = min(K, total); s_cnt = c; s_nq = c; }
         if (total > SP_SLOTS) __syncthreads();                                  // zeroed words reach into the key area
     };
@@ -492,7 +500,7 @@ __global__ __launch_bounds__(II_BLOCK, 3) void item_sparse_topk_kernel(ItemItemP
     for (int64_t base = hb; base < he; base += SP_HIST) {
         const int m = (int)min((int64_t)SP_HIST, he - base);
         if (base != hb) __syncthreads();
-        for (int e = tid; e < m; e += II_BLOCK) { hj[e] = p.h_idx[base + e]; hx[e] = p.h_val[base + e]; }
+        for (int e = tid; e < m; e += SP_BLOCK) { hj[e] = p.h_idx[base + e]; hx[e] = p.h_val[base + e]; }
         __syncthreads();
         for (int e = g; e < m; e += SP_NG) {
             const int64_t *cp = p.cptr + (int64_t)hj[e] * nc1;
@@ -502,11 +510,12 @@ __global__ __launch_bounds__(II_BLOCK, 3) void item_sparse_topk_kernel(ItemItemP
     }
     if (n_ex > 0) {
         __syncthreads();
-        for (int c = tid + 1; c < nc1; c += II_BLOCK)
+        for (int c = tid + 1; c < nc1; c += SP_BLOCK)
             Tc[c] += (unsigned long long)ex_lower_bound(c >= (1 << 30) / SP_CHUNK ? 0x7fffffff : c * SP_CHUNK);
     }
     __syncthreads();
 
+    if (p.dbg == 101) return;                             // dev ablation 101..105: cumulative early exits, timing only
     // equal shares: ceil(total / cap) passes of about total / passes entries keep the table load even
     unsigned long long cap = (unsigned long long)p.sp_cap;
     {
@@ -543,6 +552,7 @@ __global__ __launch_bounds__(II_BLOCK, 3) void item_sparse_topk_kernel(ItemItemP
                 }
             });
             walk(ca, cb, [&](const int (&c)[4], const float (&w)[4], const bool (&ok)[4], double x) {
+                if (p.dbg == 102) { if (c[0] + c[1] + c[2] + c[3] + __float_as_int(w[0] + w[1] + w[2] + w[3]) == 0x7ffffff1) vals[0] = 1ull; return; }
                 // every round probes all four entries (finished ones with key 0: CAS(0 -> 0) changes nothing)
                 uint32_t key[4];
                 int slot[4];
@@ -553,36 +563,42 @@ __global__ __launch_bounds__(II_BLOCK, 3) void item_sparse_topk_kernel(ItemItemP
                     slot[t] = sp_slot(c[t]);
                     val[t] = fixed(w[t], x);
                 }
-                for (int round = 0;; ++round) {
-                    uint32_t old[4];
-                    if (round == 0) {
+                uint32_t old[4];
 #pragma unroll
-                        for (int t = 0; t < 4; ++t) old[t] = atomicCAS(&keys[slot[t]], 0u, key[t]);
-                    } else {
+                for (int t = 0; t < 4; ++t) { old[t] = 0u; if (key[t] != 0u) old[t] = atomicCAS(&keys[slot[t]], 0u, key[t]); }
 #pragma unroll
-                        for (int t = 0; t < 4; ++t) { old[t] = 0u; if (key[t] != 0u) old[t] = atomicCAS(&keys[slot[t]], 0u, key[t]); }
+                for (int t = 0; t < 4; ++t) {
+                    const bool hit = old[t] == 0u || (old[t] & ~SP_FLAG) == key[t];
+                    if (hit && key[t] != 0u && !(old[t] & SP_FLAG)) atomicAdd(&vals[slot[t]], val[t]);
+                    key[t] = hit ? 0u : key[t];
+                }
+                // the entries whose slot belongs to another column walk on, one entry at a time: only their lanes run
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    while (key[t] != 0u) {
+                        slot[t] = slot[t] + 1 == SP_SLOTS ? 0 : slot[t] + 1;
+                        const uint32_t o = atomicCAS(&keys[slot[t]], 0u, key[t]);
+                        if (o == 0u || (o & ~SP_FLAG) == key[t]) {
+                            if (!(o & SP_FLAG)) atomicAdd(&vals[slot[t]], val[t]);
+                            key[t] = 0u;
+                        }
                     }
-                    bool more = false;
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        const bool hit = key[t] == 0u || old[t] == 0u || (old[t] & ~SP_FLAG) == key[t];
-                        if (hit && key[t] != 0u && !(old[t] & SP_FLAG)) atomicAdd(&vals[slot[t]], val[t]);
-                        key[t] = hit ? 0u : key[t];
-                        const int nx = slot[t] + 1 == SP_SLOTS ? 0 : slot[t] + 1;
-                        slot[t] = hit ? slot[t] : nx;
-                        more |= !hit;
-                    }
-                    if (!__any(more)) break;
                 }
             });
             __syncthreads();
+            if (p.dbg == 102) { ca = cb; continue; }
+            if (p.dbg == 103) {
+                for (int v = 0; v < SP_SPT; ++v) { keys[tid + v * SP_BLOCK] = 0u; vals[tid + v * SP_BLOCK] = 0ull; }
+                ca = cb;
+                continue;
+            }
             // ---- table slots -> sort keys in registers; the slots are left empty
             uint32_t kk[SP_SPT];
             unsigned long long av[SP_SPT];
 #pragma unroll
-            for (int v = 0; v < SP_SPT; ++v) { kk[v] = keys[tid + v * II_BLOCK]; av[v] = vals[tid + v * II_BLOCK]; }
+            for (int v = 0; v < SP_SPT; ++v) { kk[v] = keys[tid + v * SP_BLOCK]; av[v] = vals[tid + v * SP_BLOCK]; }
 #pragma unroll
-            for (int v = 0; v < SP_SPT; ++v) { keys[tid + v * II_BLOCK] = 0u; vals[tid + v * II_BLOCK] = 0ull; }
+            for (int v = 0; v < SP_SPT; ++v) { keys[tid + v * SP_BLOCK] = 0u; vals[tid + v * SP_BLOCK] = 0ull; }
 #pragma unroll
             for (int v = 0; v < SP_REG; ++v) {
                 kreg[v] = 0ull;
@@ -608,8 +624,8 @@ __global__ __launch_bounds__(II_BLOCK, 3) void item_sparse_topk_kernel(ItemItemP
 #pragma unroll
             for (int v = 0; v < SP_REG; ++v) {
                 kreg[v] = 0ull;
-                if (v >= SP_CHUNK / II_BLOCK) continue;
-                const int lc = tid + v * II_BLOCK;
+                if (v >= SP_CHUNK / SP_BLOCK) continue;
+                const int lc = tid + v * SP_BLOCK;
                 const uint32_t bit = 1u << (lc & 31);
                 if (!(tbm[lc >> 5] & bit)) continue;
                 const long long a = (long long)raw[lc];
@@ -622,6 +638,14 @@ __global__ __launch_bounds__(II_BLOCK, 3) void item_sparse_topk_kernel(ItemItemP
                 if (s == 0.0f) s = 0.0f;
                 kreg[v] = sp_key(s, col);
             }
+        }
+        if (p.dbg == 104) {
+            if (dense) { __syncthreads(); if (tid < 2 * (SP_CHUNK / 32)) tbm[tid] = 0u; }
+            unsigned long long z = 0;
+            for (int v = 0; v < SP_REG; ++v) z ^= kreg[v];
+            if (z == 0x1234567ull) top[0] = z;
+            ca = cb;
+            continue;
         }
         // ---- bound: the list's K-th key, or (list not full) the best wave's K-th best thread maximum
         const int cnt = s_cnt;
@@ -643,7 +667,7 @@ __global__ __launch_bounds__(II_BLOCK, 3) void item_sparse_topk_kernel(ItemItemP
         if (cnt < K) {
             uint32_t th = 0u;
 #pragma unroll
-            for (int w = 0; w < II_BLOCK / 64; ++w) th = max(th, wred[w]);
+            for (int w = 0; w < SP_BLOCK / 64; ++w) th = max(th, wred[w]);
             tau = th ? ((unsigned long long)th << 32) - 1ull : 0ull;
         } else tau = top[K - 1];
         if (dense && tid < 2 * (SP_CHUNK / 32)) tbm[tid] = 0u;                  // tbm and xbm are contiguous
@@ -658,6 +682,7 @@ __global__ __launch_bounds__(II_BLOCK, 3) void item_sparse_topk_kernel(ItemItemP
         ca = cb;
     }
     __syncthreads();
+    if (p.dbg >= 101) return;
 
     // ---- untouched columns (score 0 * col_scale): only when they can still enter the list
     {
@@ -676,8 +701,8 @@ __global__ __launch_bounds__(II_BLOCK, 3) void item_sparse_topk_kernel(ItemItemP
             __syncthreads();
             int mine = 0;
             uint32_t okbits = 0;
-            for (int v = 0; v < 16; ++v) {
-                const int lc = 16 * tid + v;
+            for (int v = 0; v < SP_ZC; ++v) {
+                const int lc = SP_ZC * tid + v;
                 const int col = c0 + lc;
                 bool ok = col < p.n_items && !((zbm[lc >> 5] >> (lc & 31)) & 1u);
                 if (ok && p.pen != nullptr) { const float z = 0.0f * p.pen[col]; ok = z == z; }
@@ -690,12 +715,12 @@ __global__ __launch_bounds__(II_BLOCK, 3) void item_sparse_topk_kernel(ItemItemP
             if (lane == 63) wred[wave] = (uint32_t)incl;
             __syncthreads();
             int before = incl - mine, all = 0;
-            for (int w = 0; w < II_BLOCK / 64; ++w) { if (w < wave) before += (int)wred[w]; all += (int)wred[w]; }
+            for (int w = 0; w < SP_BLOCK / 64; ++w) { if (w < wave) before += (int)wred[w]; all += (int)wred[w]; }
             if (tid < SP_CHUNK / 32) zbm[tid] = 0u;
             if (tid < cnt) qkey[tid] = top[tid];
             before += found;
-            for (int v = 0; v < 16 && before < K; ++v)
-                if (okbits & (1u << v)) { qkey[atomicAdd(&s_nq, 1)] = sp_key(0.0f, c0 + 16 * tid + v); ++before; }
+            for (int v = 0; v < SP_ZC && before < K; ++v)
+                if (okbits & (1u << v)) { qkey[atomicAdd(&s_nq, 1)] = sp_key(0.0f, c0 + SP_ZC * tid + v); ++before; }
             found += all;
             __syncthreads();
             rank_merge();
@@ -713,9 +738,18 @@ __global__ __launch_bounds__(II_BLOCK, 3) void item_sparse_topk_kernel(ItemItemP
 
 int launch_item_sparse_topk(const ItemItemParams &p, int32_t *out_ids, float *out_scores, hipStream_t stream)
 {
-    if (p.n <= 0 || p.n > (int64_t)0xffffffffu / II_BLOCK || p.K < 1 || p.K > 32) return -1;
+    if (p.n <= 0 || p.n > (int64_t)0xffffffffu / SP_BLOCK || p.K < 1 || p.K > 32) return -1;
     if (p.n_chunks < 1 || p.n_chunks > SP_MAXCH || p.sp_cap < 1 || p.sp_cap > SP_CAP) return -1;
-    hipLaunchKernelGGL(item_sparse_topk_kernel, dim3((unsigned)p.n), dim3(II_BLOCK), 0, stream, p, out_ids, out_scores);
+    static bool attr_done[64] = {false};                 // more than 64 KB of LDS needs the opt-in, once per device
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return -3;
+    bool &attr_set = attr_done[dev];
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(item_sparse_topk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)SP_LDS_BYTES) != hipSuccess) return -3;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(item_sparse_topk_kernel, dim3((unsigned)p.n), dim3(SP_BLOCK), SP_LDS_BYTES, stream, p, out_ids, out_scores);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 int item_sparse_pass_capacity() { return SP_CAP; }

@@ -10,11 +10,13 @@ sc.set_item_matrix_csr(w["m_ptr"], w["m_idx"], w["m_val"], w["n_items"], w["col_
 sc.set_history_csr(w["h_ptr"], w["h_idx"], w["h_val"])
 sc.set_exclusion_csr(w["excl_ptr"], w["excl_idx"])
 users = np.arange(nu, dtype=np.int32)
-for dbg in [int(a) for a in (sys.argv[2].split(",") if len(sys.argv) > 2 else ["0"])]:
+caps = [int(a) for a in sys.argv[3].split(",")] if len(sys.argv) > 3 else [0]
+for dbg, cap in [(int(a), c) for a in (sys.argv[2].split(",") if len(sys.argv) > 2 else ["0"]) for c in caps]:
     sc.set_option("debug_mode", dbg)
+    sc.set_option("csr_pass_entries", cap)
     sc.rank_topk(users, 10); torch.cuda.synchronize()
     t = time.perf_counter()
     for _ in range(3): sc.rank_topk(users, 10)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t) / 3
-    print(f"dbg {dbg}: {dt*1e3:.2f} ms  {nu/dt/1e6:.2f} M users/s", flush=True)
+    print(f"dbg {dbg} cap {cap}: {dt*1e3:.2f} ms  {nu/dt/1e6:.2f} M users/s", flush=True)
