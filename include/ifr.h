@@ -85,6 +85,18 @@ int ifr_set_item_matrix_dense(ifr_handle h, const float *M, int64_t n_items, int
 int ifr_set_item_matrix_csr(ifr_handle h, const int64_t *indptr, const int32_t *indices, const float *values,
                             int64_t n_items, int64_t nnz, const float *col_scale);
 
+/* EASE model build on the device, cornac/models/ease/recom_ease.py:75-95:
+ *     G = X^T X + lamb I,  P = G^-1,  B = P / (-diag P) column-wise,  diag B = 0,  posB: B[B < 0] = 0
+ * X = train_set.matrix as CSR [n_users][n_items] (columns strictly ascending inside a row, finite
+ * ratings; "any" pointers).  G and P are fp64 like the reference's (Gram by fp64 atomics: exact for
+ * integer ratings, else order-dependent in the last bits; inverse by Cholesky, the reference uses LU:
+ * equal to ~1e-10 relative, tests/test_gpu_fit.py).  B becomes the handle's dense item matrix exactly
+ * as if it had been passed to ifr_set_item_matrix_dense (fp32, no col_scale); call ifr_set_history_csr
+ * next.  B_out: host fp64 [n_items][n_items] row-major copy of B, or NULL.  Needs 16 * n_items^2 bytes
+ * of device memory while it runs. */
+int ifr_fit_ease(ifr_handle h, const int64_t *x_indptr, const int32_t *x_indices, const float *x_values, int64_t n_users,
+                 int64_t n_items, int64_t nnz, double lamb, int posB, double *B_out);
+
 /* Per-user histories of an item-item model: row u = the items and weights x_uj that enter user u's
  * score (EASE: train_set.matrix, recom_ease.py:75; RP3-beta: the user's train items, each weighted
  * 1/deg(u), graph_recommender.py:53-55).  Users >= n_rows have an empty history (score 0).

@@ -14,6 +14,7 @@
 #include "../../include/ifr.h"
 #include "ifr_kernels.h"
 #include "ifr_itemitem.h"
+#include "ifr_fit.h"
 
 namespace ifr {
 // implemented in ifr_aux.hip
@@ -61,6 +62,7 @@ struct ifr_handle_s {
     int64_t tr_rows = 0, tr_nnz = 0;
     int tr_max_row = 0;
     // workspaces (grow-only)
+    void *rocblas = nullptr;     // rocBLAS handle of the model build entry points (created on first use)
     void *ws_part = nullptr; size_t ws_part_bytes = 0;
     void *ws_met = nullptr; size_t ws_met_bytes = 0;
     void *ws_sort = nullptr; size_t ws_sort_bytes = 0;
@@ -237,6 +239,7 @@ int ifr_destroy(ifr_handle h)
     dfree(h->iiM); dfree(h->ii_cptr); dfree(h->ii_idx); dfree(h->ii_val); dfree(h->ii_pen);
     dfree(h->hs_ptr); dfree(h->hs_idx); dfree(h->hs_val);
     dfree(h->ws_part); dfree(h->ws_met); dfree(h->ws_sort);
+    ifr::ease_release(&h->rocblas);
     for (auto &e : h->ev_used) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     for (auto &e : h->ev_free) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     delete h;
@@ -393,6 +396,67 @@ int ifr_set_item_matrix_dense(ifr_handle h, const float *M, int64_t n_items, int
     h->ii_ld = ldm;
     h->ii_chunks = (int)((n_items + chunk - 1) / chunk);
     int rc = set_col_scale(h, col_scale, n_items, (int64_t)h->ii_chunks * chunk);
+    if (rc) return rc;
+    h->n_items = n_items; h->n_users = 0; h->mode = MODE_ITEM_DENSE; h->opt_catalogue = 0;
+    return IFR_OK;
+}
+
+int ifr_fit_ease(ifr_handle h, const int64_t *x_indptr, const int32_t *x_indices, const float *x_values, int64_t n_users,
+                 int64_t n_items, int64_t nnz, double lamb, int posB, double *B_out)
+{
+    if (!h) return IFR_ERR_ARG;
+    if (!x_indptr || n_users < 0 || n_items <= 0 || nnz < 0 || (nnz > 0 && (!x_indices || !x_values)))
+        return fail(h, IFR_ERR_ARG, "ifr_fit_ease: null/empty input");
+    if (n_items > (int64_t)1 << 30) return fail(h, IFR_ERR_ARG, "ifr_fit_ease: n_items too large");
+    if (!(lamb == lamb)) return fail(h, IFR_ERR_ARG, "ifr_fit_ease: lamb is NaN");
+    IFR_HIP(h, hipSetDevice(h->device));
+    const int64_t old_items = h->n_items;
+    clear_factor_model(h);
+    clear_item_model(h);
+    h->n_items = old_items;
+    drop_csrs_if_catalogue_changes(h, n_items);
+    h->n_items = 0;
+    // X on the device, validated: item indices in range and strictly ascending inside a row, finite values
+    int64_t *d_ptr = nullptr;
+    int32_t *d_idx = nullptr;
+    float *d_val = nullptr;
+    int *d_flags = nullptr;
+    std::vector<int64_t> hp;
+    auto cleanup = [&]() { dfree(d_ptr); dfree(d_idx); dfree(d_val); dfree(d_flags); };
+    int rc = copy_csr(h, x_indptr, x_indices, n_users, nnz, &d_ptr, &d_idx, &hp);
+    if (rc) { cleanup(); return rc; }
+    uint32_t flags[2] = {0, 0};
+    bool ok = hipMalloc((void **)&d_val, sizeof(float) * std::max<int64_t>(nnz, 1)) == hipSuccess &&
+              (nnz == 0 || hipMemcpy(d_val, x_values, sizeof(float) * nnz, hipMemcpyDefault) == hipSuccess) &&
+              hipMalloc((void **)&d_flags, 2 * sizeof(int)) == hipSuccess && hipMemset(d_flags, 0, 2 * sizeof(int)) == hipSuccess &&
+              (n_users == 0 || ifr::launch_validate_csr(d_ptr, d_idx, n_users, (int)n_items, 1, d_flags, 0) == 0) &&
+              (nnz == 0 || ifr::launch_absmax(d_val, nnz, (uint32_t *)d_flags + 1, 0) == 0) &&
+              hipDeviceSynchronize() == hipSuccess && hipMemcpy(flags, d_flags, sizeof(flags), hipMemcpyDeviceToHost) == hipSuccess;
+    float amax;
+    memcpy(&amax, &flags[1], sizeof(float));
+    if (!ok || flags[0] != 0 || !std::isfinite(amax)) {
+        cleanup();
+        return fail(h, ok ? IFR_ERR_ARG : IFR_ERR_HIP,
+                    !ok ? "ifr_fit_ease: device set-up failed"
+                        : flags[0] ? "ifr_fit_ease: item index outside [0, n_items) or not strictly ascending inside a row"
+                                   : "ifr_fit_ease: non-finite rating");
+    }
+    const int chunk = ifr::item_item_chunk(false), pass = ifr::item_item_pass();
+    const int64_t ldm = (n_items + pass - 1) / pass * pass;
+    if (hipMalloc((void **)&h->iiM, sizeof(float) * n_items * ldm) != hipSuccess ||
+        hipMemset(h->iiM, 0, sizeof(float) * n_items * ldm) != hipSuccess) {
+        cleanup(); clear_item_model(h);
+        return fail(h, IFR_ERR_HIP, "ifr_fit_ease: device memory for B");
+    }
+    char msg[256] = "";
+    if (ifr::ease_build(d_ptr, d_idx, d_val, n_users, n_items, lamb, posB, h->iiM, ldm, B_out, &h->rocblas, msg, sizeof(msg))) {
+        cleanup(); clear_item_model(h);
+        return fail(h, IFR_ERR_HIP, msg);
+    }
+    cleanup();
+    h->ii_ld = ldm;
+    h->ii_chunks = (int)((n_items + chunk - 1) / chunk);
+    rc = set_col_scale(h, nullptr, n_items, (int64_t)h->ii_chunks * chunk);
     if (rc) return rc;
     h->n_items = n_items; h->n_users = 0; h->mode = MODE_ITEM_DENSE; h->opt_catalogue = 0;
     return IFR_OK;

@@ -139,6 +139,23 @@ class HipScorer:
         self.has_exclusions = False
         del km, kc
 
+    def fit_ease(self, indptr, indices, values, n_items, lamb, posB=True, want_B=False):
+        """EASE closed form on the device (recom_ease.py:75-95) from X = train_set.matrix (CSR); B becomes the
+        dense item matrix of this scorer.  want_B: also return B as a host float64 [I, I] array."""
+        pp, kp = self._any_ptr(indptr, np.int64)
+        pi, ki = self._any_ptr(indices, np.int32)
+        pv, kv = self._any_ptr(values, np.float32)
+        n_items = int(n_items)
+        B = np.empty((n_items, n_items), np.float64) if want_B else None
+        self._check(self._lib.ifr_fit_ease(self._h, pp, pi, pv, len(indptr) - 1, n_items, len(indices), float(lamb),
+                                           int(bool(posB)), _host_ptr(B) if want_B else None))
+        self.n_items, self.k, self.n_users = n_items, 0, 0
+        self.catalogue_items = n_items
+        self.item_model = "dense"
+        self.has_exclusions = False
+        del kp, ki, kv
+        return B
+
     def set_item_matrix_csr(self, indptr, indices, values, n_items, col_scale=None):
         """Item-item model with a sparse M (CSR rows, strictly ascending columns)."""
         pp, kp = self._any_ptr(indptr, np.int64)

@@ -342,6 +342,10 @@ class ItemItemScoringMixin(HipScoringMixin):
                                     M.data.astype(np.float32), M.shape[0], col_scale)
         else:
             eng.set_item_matrix_dense(M, col_scale)
+        self._hip_set_histories(eng, hist)
+
+    def _hip_set_histories(self, eng, hist):
+        import scipy.sparse as sp
         hist = sp.csr_matrix(hist)
         eng.set_history_csr(hist.indptr.astype(np.int64), hist.indices.astype(np.int32), hist.data.astype(np.float32))
         self._hip_zero_row = max(int(self.total_users or 0), hist.shape[0])     # a user without history
@@ -353,22 +357,46 @@ class ItemItemScoringMixin(HipScoringMixin):
 class EASE(ItemItemScoringMixin, RecommenderBase):
     """cornac.models.EASE scoring (cornac/models/ease/recom_ease.py:99-126): s = X[u, :] . B with
     X = train_set.matrix (:75).  init_params: {'B': [I, I]}; without it `fit` builds B with the
-    reference's closed form (:78-95) on the host -- a one-off model build step outside the hot
-    path."""
+    reference's closed form (:78-95) -- build="device": Gram scatter + rocSOLVER Cholesky on the GPU
+    (ifr_fit_ease; B goes straight into the scoring engine, `self.B` is its float64 host copy up to
+    `device_B_copy_max_items` items and None above), build="host": the reference's NumPy expressions."""
+
+    device_B_copy_max_items = 16384          # 2 GiB of float64 on the host
 
     def __init__(self, name="EASEᴿ", lamb=500, posB=True, trainable=True, verbose=True, seed=None, B=None, U=None,
-                 init_params=None, **kwargs):
+                 init_params=None, build="device", **kwargs):
         RecommenderBase.__init__(self, name=name, trainable=trainable, verbose=verbose)
         self.lamb, self.posB, self.seed = lamb, posB, seed
         self.B = B if B is not None else (init_params or {}).get("B")
         self.U = U
+        if build not in ("device", "host"):
+            raise ValueError("build must be 'device' or 'host'")
+        self.build = build
 
     def fit(self, train_set, val_set=None):
+        import scipy.sparse as sp
         RecommenderBase.fit(self, train_set, val_set)
         self.U = train_set.matrix                                   # recom_ease.py:75
+        self.hip_invalidate()
         if self.B is None:
             if not self.trainable:
                 raise ValueError("EASE(trainable=False) needs init_params={'B': ...}")
+            if self.build == "device":
+                from .engine import HipScorer
+                X = sp.csr_matrix(self.U)
+                X.sum_duplicates()
+                X.sort_indices()
+                eng = HipScorer(self.hip_device)
+                try:
+                    n_items = X.shape[1]
+                    self.B = eng.fit_ease(X.indptr.astype(np.int64), X.indices.astype(np.int32), X.data.astype(np.float32),
+                                          n_items, self.lamb, self.posB, want_B=n_items <= self.device_B_copy_max_items)
+                    self._hip_set_histories(eng, X)
+                except Exception:
+                    eng.close()
+                    raise
+                self._hip = eng                                     # B is already resident: no second upload
+                return self
             G = self.U.T.dot(self.U).toarray()                      # :78
             di = np.diag_indices(G.shape[0])
             G[di] = G.diagonal() + self.lamb
@@ -378,10 +406,12 @@ class EASE(ItemItemScoringMixin, RecommenderBase):
             if self.posB:
                 B[B < 0] = 0
             self.B = B
-        self.hip_invalidate()
         return self
 
     def _hip_item_model(self):
+        if self.B is None:
+            raise RuntimeError("EASE: B was built on the device and not copied back (more than device_B_copy_max_items "
+                               "items); it went with the engine that hip_invalidate() closed -- call fit() again")
         return self.B, self.U, None
 
     def _hip_shape_scores(self, scores):

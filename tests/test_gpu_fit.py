@@ -1,0 +1,83 @@
+"""GPU tests of the model build entry point ifr_fit_ease through the C ABI.
+
+Bars: B against the reference's own EASE.fit output (tests/golden/toy_all_models.npz, made by
+tests/golden/make_golden.py) and against the reference's closed form restated in NumPy fp64
+(recom_ease.py:78-95): 1e-8 relative to the largest entry (Cholesky here, LU there); the fp32 matrix the
+scoring kernels read is exactly fl32(B)."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from test_oracle import _csr
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch
+
+
+def _closed_form(X, lamb, posB):
+    G = X.T.dot(X).toarray().astype(np.float64)
+    di = np.diag_indices(G.shape[0])
+    G[di] = G.diagonal() + lamb
+    P = np.linalg.inv(G)
+    B = P / (-np.diag(P))
+    B[di] = 0.0
+    if posB:
+        B[B < 0] = 0
+    return B
+
+
+def test_ease_fit_matches_reference_output(torch, toy):
+    from recommenders_amd.data import Dataset
+    from recommenders_amd.models import EASE
+    d = toy
+    train_set = Dataset.from_csr(_csr(d, "train"))
+    dev = EASE(lamb=50, posB=True, build="device").fit(train_set)
+    ref_B = d["ease_B"]
+    np.testing.assert_allclose(dev.B, ref_B, rtol=0, atol=1e-8 * np.abs(ref_B).max())
+    assert (np.diag(dev.B) == 0).all() and (dev.B >= 0).all()
+    # the device-resident model scores like the one uploaded from the reference's B
+    host = EASE(lamb=50, trainable=False, init_params={"B": ref_B}).fit(train_set)
+    for u in (0, 3, train_set.num_users - 1):
+        np.testing.assert_allclose(dev.score(u), host.score(u), rtol=1e-6, atol=1e-9)
+        a, b = dev.rank(u, k=5)[0], host.rank(u, k=5)[0]
+        assert set(a.tolist()) == set(b.tolist())
+
+
+@pytest.mark.parametrize("posB,ratings", [(False, True), (True, False)])
+def test_ease_fit_matches_closed_form_and_installs_fl32_B(torch, posB, ratings):
+    from recommenders_amd import HipScorer
+    rng = np.random.default_rng(5)
+    n_users, n_items = 3000, 1537
+    X = sp.random(n_users, n_items, density=0.02, format="csr", dtype=np.float32, random_state=np.random.RandomState(5),
+                  data_rvs=lambda n: (rng.integers(1, 6, n) if ratings else np.ones(n)).astype(np.float32))
+    X.sort_indices()
+    sc = HipScorer(0)
+    B = sc.fit_ease(X.indptr.astype(np.int64), X.indices, X.data, n_items, 500.0, posB, want_B=True)
+    ref = _closed_form(X.astype(np.float64), 500.0, posB)
+    np.testing.assert_allclose(B, ref, rtol=0, atol=1e-8 * np.abs(ref).max())
+    # one-item histories read rows of the installed matrix: exactly fl32(B)
+    items = np.array([0, 7, 1024, n_items - 1], np.int32)
+    sc.set_history_csr(np.arange(len(items) + 1, dtype=np.int64), items, np.ones(len(items), np.float32))
+    rows = sc.score_dense(np.arange(len(items), dtype=np.int32)).cpu().numpy()
+    np.testing.assert_array_equal(rows[:, :n_items], B[items].astype(np.float32))
+    sc.close()
+
+
+def test_ease_fit_rejects_bad_input(torch):
+    from recommenders_amd import HipScorer
+    sc = HipScorer(0)
+    ptr = np.array([0, 2], np.int64)
+    with pytest.raises(RuntimeError, match="ascending"):
+        sc.fit_ease(ptr, np.array([3, 1], np.int32), np.ones(2, np.float32), 5, 10.0)
+    with pytest.raises(RuntimeError, match="positive definite"):
+        sc.fit_ease(ptr, np.array([1, 3], np.int32), np.ones(2, np.float32), 5, 0.0)      # items 0, 2, 4 never seen
+    with pytest.raises(RuntimeError, match="non-finite"):
+        sc.fit_ease(ptr, np.array([1, 3], np.int32), np.array([1.0, np.inf], np.float32), 5, 10.0)
+    sc.close()

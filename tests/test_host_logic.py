@@ -222,7 +222,7 @@ def test_rp3_fit_builds_item_item_form_and_leaves_the_dataset_alone(toy):
     np.testing.assert_array_equal(np.asarray(M), W32.toarray())
     np.testing.assert_array_equal(col_scale, pen)
     # EASE.fit: the closed form of recom_ease.py:78-95 reproduces the reference's B
-    e = EASE(lamb=50, posB=True, trainable=True).fit(train_set)
+    e = EASE(lamb=50, posB=True, trainable=True, build="host").fit(train_set)
     np.testing.assert_allclose(e.B, d["ease_B"], rtol=1e-9, atol=1e-12)
     np.testing.assert_array_equal(train_set.csr_matrix.data, before)
 
