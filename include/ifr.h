@@ -104,6 +104,16 @@ int ifr_fit_ease(ifr_handle h, const int64_t *x_indptr, const int32_t *x_indices
 int ifr_set_history_csr(ifr_handle h, const int64_t *indptr, const int32_t *indices, const float *values,
                         int64_t n_rows, int64_t nnz);
 
+/* RP3-beta model build on the device, cornac/models/rp3_beta/graph_recommender.py:24-55, 83-84, 104-115 in
+ * item-item form: P_ui = A / deg(u), P_iu = A^T / deg(item), W = P_iu . P_ui (fp64 sparse product like the
+ * reference's SciPy one, rounded to fp32), col_scale = 1 / deg(item)^beta from the integer degrees.
+ * A = the binarised train matrix as a CSR pattern [n_users][n_items] (the interactions with rating > 0,
+ * recom_rp3beta.py:76; columns strictly ascending; "any" pointers).  Installs W as the CSR item matrix
+ * (as ifr_set_item_matrix_csr would) and P_ui as the histories (as ifr_set_history_csr would); the
+ * reference's (U+I)^2 cube P^3 is never built.  w_nnz: entries of W, or NULL. */
+int ifr_fit_rp3beta(ifr_handle h, const int64_t *a_indptr, const int32_t *a_indices, int64_t n_users, int64_t n_items, int64_t nnz,
+                    double beta, int64_t *w_nnz);
+
 /* The power-of-two scale of the fixed-point accumulation of a CSR item matrix, derived from
  * max|M| and the largest history L1 norm so that no sum can overflow; lets a CPU checker
  * reproduce the scores bit-for-bit (no reference counterpart).  Needs matrix and histories set. */

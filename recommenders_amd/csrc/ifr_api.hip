@@ -63,6 +63,7 @@ struct ifr_handle_s {
     int tr_max_row = 0;
     // workspaces (grow-only)
     void *rocblas = nullptr;     // rocBLAS handle of the model build entry points (created on first use)
+    void *rocsparse = nullptr;   // rocSPARSE handle, likewise
     void *ws_part = nullptr; size_t ws_part_bytes = 0;
     void *ws_met = nullptr; size_t ws_met_bytes = 0;
     void *ws_sort = nullptr; size_t ws_sort_bytes = 0;
@@ -240,6 +241,7 @@ int ifr_destroy(ifr_handle h)
     dfree(h->hs_ptr); dfree(h->hs_idx); dfree(h->hs_val);
     dfree(h->ws_part); dfree(h->ws_met); dfree(h->ws_sort);
     ifr::ease_release(&h->rocblas);
+    ifr::rp3_release(&h->rocsparse);
     for (auto &e : h->ev_used) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     for (auto &e : h->ev_free) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     delete h;
@@ -562,6 +564,54 @@ int ifr_set_history_csr(ifr_handle h, const int64_t *indptr, const int32_t *indi
     }
     h->hs_rows = n_rows; h->hs_nnz = nnz; h->hs_l1max = l1; h->n_users = n_rows;
     return IFR_OK;
+}
+
+int ifr_fit_rp3beta(ifr_handle h, const int64_t *a_indptr, const int32_t *a_indices, int64_t n_users, int64_t n_items, int64_t nnz,
+                    double beta, int64_t *w_nnz)
+{
+    if (!h) return IFR_ERR_ARG;
+    if (!a_indptr || n_users < 0 || n_items <= 0 || nnz < 0 || (nnz > 0 && !a_indices))
+        return fail(h, IFR_ERR_ARG, "ifr_fit_rp3beta: null/empty input");
+    if (n_items > (int64_t)1 << 30) return fail(h, IFR_ERR_ARG, "ifr_fit_rp3beta: n_items too large");
+    if (!(beta == beta)) return fail(h, IFR_ERR_ARG, "ifr_fit_rp3beta: beta is NaN");
+    IFR_HIP(h, hipSetDevice(h->device));
+    int64_t *d_ptr = nullptr;
+    int32_t *d_idx = nullptr;
+    int *d_flags = nullptr;
+    std::vector<int64_t> hp;
+    ifr::Rp3Arrays arr;
+    memset(&arr, 0, sizeof(arr));
+    auto cleanup = [&]() { dfree(d_ptr); dfree(d_idx); dfree(d_flags); ifr::rp3_free(&arr); };
+    int rc = copy_csr(h, a_indptr, a_indices, n_users, nnz, &d_ptr, &d_idx, &hp);
+    if (rc) { cleanup(); return rc; }
+    uint32_t flag = 0;
+    bool ok = hipMalloc((void **)&d_flags, 2 * sizeof(int)) == hipSuccess && hipMemset(d_flags, 0, 2 * sizeof(int)) == hipSuccess &&
+              (n_users == 0 || ifr::launch_validate_csr(d_ptr, d_idx, n_users, (int)n_items, 1, d_flags, 0) == 0) &&
+              hipDeviceSynchronize() == hipSuccess && hipMemcpy(&flag, d_flags, sizeof(flag), hipMemcpyDeviceToHost) == hipSuccess;
+    if (!ok || flag != 0) {
+        cleanup();
+        return fail(h, ok ? IFR_ERR_ARG : IFR_ERR_HIP,
+                    ok ? "ifr_fit_rp3beta: item index outside [0, n_items) or not strictly ascending inside a row"
+                       : "ifr_fit_rp3beta: device set-up failed");
+    }
+    char msg[256] = "";
+    if (ifr::rp3_build(d_ptr, d_idx, n_users, n_items, nnz, &h->rocsparse, &arr, msg, sizeof(msg))) {
+        cleanup();
+        return fail(h, IFR_ERR_HIP, msg);
+    }
+    // col_scale = 1 / deg(item)^beta from the integer degrees (graph_recommender.py:104-115; degree 0 -> inf)
+    std::vector<int64_t> deg(n_items);
+    if (hipMemcpy(deg.data(), arr.deg, sizeof(int64_t) * n_items, hipMemcpyDeviceToHost) != hipSuccess) {
+        cleanup();
+        return fail(h, IFR_ERR_HIP, "ifr_fit_rp3beta: reading the item degrees");
+    }
+    std::vector<float> pen(n_items);
+    for (int64_t i = 0; i < n_items; ++i) pen[i] = (float)(1.0 / std::pow((double)deg[i], beta));
+    rc = ifr_set_item_matrix_csr(h, arr.w_ptr, arr.w_idx, arr.w_val, n_items, arr.w_nnz, pen.data());
+    if (!rc) rc = ifr_set_history_csr(h, d_ptr, d_idx, arr.p_val32, n_users, nnz);
+    if (w_nnz) *w_nnz = arr.w_nnz;
+    cleanup();
+    return rc;
 }
 
 int ifr_item_fixed_point_shift(ifr_handle h, int *shift)

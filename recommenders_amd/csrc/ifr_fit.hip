@@ -4,6 +4,12 @@
 //     G = X^T X + lamb I          (X = train_set.matrix, CSR [users][items])
 //     P = G^-1
 //     B = P / (-diag P)  column-wise,  diag B = 0,  posB: negative entries -> 0
+//
+// RP3-beta item-item form, cornac/models/rp3_beta/graph_recommender.py:24-55, 83-84, 104-115:
+//     P_ui = A / deg(u),  P_iu = A^T / deg(i),  W = P_iu . P_ui   (A = binarised train matrix)
+// instead of the reference's (U+I)^2 cube P^3: transpose by counting sort (hand-written), the sparse
+// product by rocSPARSE SpGEMM in fp64 like SciPy's, rows sorted by one radix sort of (row, column) keys.
+//
 // G and P are fp64 like the reference's.  The Gram matrix is a scatter of every user's item pairs
 // (nnz_u^2 / 2 fp64 atomics into the stored triangle: HBM-bound, no GEMM to shape: a dense X^T X
 // would do users / nnz_u times the flops); the inverse is a plain library factorisation
@@ -11,9 +17,14 @@
 // streaming kernel that writes the fp32 matrix the scoring kernels read.
 #include <hip/hip_runtime.h>
 #include <rocblas/rocblas.h>
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
+#include <rocprim/iterator/transform_iterator.hpp>
 #include <rocsolver/rocsolver.h>
+#include <rocsparse/rocsparse.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <string.h>
 
 #include "ifr_fit.h"
 
@@ -127,6 +138,176 @@ int ease_build(const int64_t *d_ptr, const int32_t *d_idx, const float *d_val, i
 void ease_release(void **rocblas_cache)
 {
     if (*rocblas_cache) { rocblas_destroy_handle((rocblas_handle)*rocblas_cache); *rocblas_cache = nullptr; }
+}
+
+// ------------------------------------------------------------------------------------ RP3-beta
+__global__ void column_count_kernel(const int32_t *idx, int64_t nnz, unsigned long long *cnt)
+{
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < nnz) atomicAdd(&cnt[idx[e]], 1ull);
+}
+
+// one thread per user row: P_ui values (1 / deg(u), fp64 and fp32) and the transposed entries
+// (item row <- user column, value 1 / deg(item)); the order inside a transposed row is arbitrary
+__global__ void rp3_transpose_kernel(const int64_t *ptr, const int32_t *idx, int64_t n_users, const int64_t *t_ptr,
+                                     unsigned long long *cursor, double *p_val, float *p_val32, int32_t *t_idx, double *t_val)
+{
+    const int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= n_users) return;
+    const int64_t b = ptr[u], e = ptr[u + 1];
+    const double pu = 1.0 / (double)(e - b);
+    for (int64_t q = b; q < e; ++q) {
+        const int32_t i = idx[q];
+        p_val[q] = pu;
+        p_val32[q] = (float)pu;
+        const int64_t pos = t_ptr[i] + (int64_t)atomicAdd(&cursor[i], 1ull);
+        t_idx[pos] = (int32_t)u;
+        t_val[pos] = 1.0 / (double)(t_ptr[i + 1] - t_ptr[i]);
+    }
+}
+
+__global__ void rp3_keys_kernel(const int64_t *ptr, const int32_t *idx, int64_t n_rows, uint64_t *keys)
+{
+    const int64_t r = blockIdx.x;
+    for (int64_t q = ptr[r] + threadIdx.x; q < ptr[r + 1]; q += blockDim.x) keys[q] = ((uint64_t)r << 32) | (uint32_t)idx[q];
+}
+
+__global__ void rp3_unpack_kernel(const uint64_t *keys, const double *val, int64_t nnz, int32_t *idx, float *val32)
+{
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < nnz) { idx[e] = (int32_t)(uint32_t)keys[e]; val32[e] = (float)val[e]; }
+}
+
+struct to_i64 {
+    __host__ __device__ int64_t operator()(unsigned long long x) const { return (int64_t)x; }
+};
+
+int rp3_build(const int64_t *a_ptr, const int32_t *a_idx, int64_t n_users, int64_t n_items, int64_t nnz, void **rocsparse_cache,
+              Rp3Arrays *out, char *err, size_t errlen)
+{
+    auto fail = [&](const char *what, int code) {
+        if (err && errlen) snprintf(err, errlen, "ifr_fit_rp3beta: %s (%d)", what, code);
+        return -1;
+    };
+    if (n_users >= 0x7fffffff || nnz >= ((int64_t)1 << 40)) return fail("too many users or interactions", 0);
+    memset(out, 0, sizeof(*out));
+    unsigned long long *cnt = nullptr, *cursor = nullptr;
+    int64_t *t_ptr = nullptr, *c_ptr = nullptr, *z_ptr = nullptr;
+    int32_t *t_idx = nullptr, *c_idx = nullptr;
+    double *p_val = nullptr, *t_val = nullptr, *c_val = nullptr, *c_val2 = nullptr;
+    uint64_t *k_in = nullptr, *k_out = nullptr;
+    void *tmp = nullptr, *buf = nullptr;
+    rocsparse_spmat_descr dA = nullptr, dB = nullptr, dC = nullptr, dD = nullptr;
+    auto cleanup = [&](bool keep_out) {
+        (void)hipFree(cnt); (void)hipFree(cursor); (void)hipFree(t_ptr); (void)hipFree(t_idx); (void)hipFree(p_val);
+        (void)hipFree(t_val); (void)hipFree(c_val); (void)hipFree(c_val2); (void)hipFree(k_in); (void)hipFree(k_out);
+        (void)hipFree(tmp); (void)hipFree(buf); (void)hipFree(c_idx); (void)hipFree(z_ptr);
+        if (dA) rocsparse_destroy_spmat_descr(dA);
+        if (dB) rocsparse_destroy_spmat_descr(dB);
+        if (dC) rocsparse_destroy_spmat_descr(dC);
+        if (dD) rocsparse_destroy_spmat_descr(dD);
+        if (!keep_out) {
+            (void)hipFree(c_ptr); (void)hipFree(out->w_idx); (void)hipFree(out->w_val); (void)hipFree(out->p_val32); (void)hipFree(out->deg);
+            memset(out, 0, sizeof(*out));
+        }
+    };
+#define FIT_HIP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { cleanup(false); return fail(#x, (int)e_); } } while (0)
+#define FIT_SP(x) do { rocsparse_status s_ = (x); if (s_ != rocsparse_status_success) { cleanup(false); return fail(#x, (int)s_); } } while (0)
+    const int64_t nz1 = nnz > 0 ? nnz : 1;
+    FIT_HIP(hipMalloc((void **)&cnt, sizeof(unsigned long long) * (n_items + 1)));
+    FIT_HIP(hipMalloc((void **)&cursor, sizeof(unsigned long long) * n_items));
+    FIT_HIP(hipMalloc((void **)&t_ptr, sizeof(int64_t) * (n_items + 1)));
+    FIT_HIP(hipMalloc((void **)&t_idx, sizeof(int32_t) * nz1));
+    FIT_HIP(hipMalloc((void **)&p_val, sizeof(double) * nz1));
+    FIT_HIP(hipMalloc((void **)&t_val, sizeof(double) * nz1));
+    FIT_HIP(hipMalloc((void **)&out->p_val32, sizeof(float) * nz1));
+    FIT_HIP(hipMalloc((void **)&out->deg, sizeof(int64_t) * n_items));
+    FIT_HIP(hipMalloc((void **)&c_ptr, sizeof(int64_t) * (n_items + 1)));
+    FIT_HIP(hipMalloc((void **)&z_ptr, sizeof(int64_t) * (n_items + 1)));                 // D = empty matrix
+    FIT_HIP(hipMemset(z_ptr, 0, sizeof(int64_t) * (n_items + 1)));
+    FIT_HIP(hipMemset(cnt, 0, sizeof(unsigned long long) * (n_items + 1)));
+    FIT_HIP(hipMemset(cursor, 0, sizeof(unsigned long long) * n_items));
+    // item degrees -> row pointers of A^T (exclusive scan)
+    if (nnz > 0) hipLaunchKernelGGL(column_count_kernel, dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, 0, a_idx, nnz, cnt);
+    size_t tmp_bytes = 0;
+    auto cnt_in = rocprim::make_transform_iterator(cnt, to_i64());
+    FIT_HIP(rocprim::exclusive_scan(nullptr, tmp_bytes, cnt_in, t_ptr, (int64_t)0, (size_t)(n_items + 1), rocprim::plus<int64_t>(), 0));
+    FIT_HIP(hipMalloc(&tmp, tmp_bytes > 0 ? tmp_bytes : 16));
+    FIT_HIP(rocprim::exclusive_scan(tmp, tmp_bytes, cnt_in, t_ptr, (int64_t)0, (size_t)(n_items + 1), rocprim::plus<int64_t>(), 0));
+    FIT_HIP(hipMemcpy(out->deg, cnt, sizeof(int64_t) * n_items, hipMemcpyDeviceToDevice));
+    if (n_users > 0)
+        hipLaunchKernelGGL(rp3_transpose_kernel, dim3((unsigned)((n_users + 255) / 256)), dim3(256), 0, 0, a_ptr, a_idx, n_users,
+                           t_ptr, cursor, p_val, out->p_val32, t_idx, t_val);
+    FIT_HIP(hipGetLastError());
+
+    rocsparse_handle sp = (rocsparse_handle)*rocsparse_cache;
+    if (!sp) {
+        FIT_SP(rocsparse_create_handle(&sp));
+        *rocsparse_cache = sp;
+    }
+    FIT_SP(rocsparse_set_stream(sp, 0));
+    // C = P_iu [items x users] . P_ui [users x items], fp64 like scipy's product
+    FIT_SP(rocsparse_create_csr_descr(&dA, n_items, n_users, nnz, t_ptr, t_idx, t_val, rocsparse_indextype_i64, rocsparse_indextype_i32,
+                                      rocsparse_index_base_zero, rocsparse_datatype_f64_r));
+    FIT_SP(rocsparse_create_csr_descr(&dB, n_users, n_items, nnz, (void *)a_ptr, (void *)a_idx, p_val, rocsparse_indextype_i64,
+                                      rocsparse_indextype_i32, rocsparse_index_base_zero, rocsparse_datatype_f64_r));
+    FIT_SP(rocsparse_create_csr_descr(&dD, n_items, n_items, 0, z_ptr, nullptr, nullptr, rocsparse_indextype_i64, rocsparse_indextype_i32,
+                                      rocsparse_index_base_zero, rocsparse_datatype_f64_r));
+    FIT_SP(rocsparse_create_csr_descr(&dC, n_items, n_items, 0, c_ptr, nullptr, nullptr, rocsparse_indextype_i64, rocsparse_indextype_i32,
+                                      rocsparse_index_base_zero, rocsparse_datatype_f64_r));
+    const double alpha = 1.0;
+    size_t buf_bytes = 0;
+    FIT_SP(rocsparse_spgemm(sp, rocsparse_operation_none, rocsparse_operation_none, &alpha, dA, dB, nullptr, dD, dC, rocsparse_datatype_f64_r,
+                            rocsparse_spgemm_alg_default, rocsparse_spgemm_stage_buffer_size, &buf_bytes, nullptr));
+    FIT_HIP(hipMalloc(&buf, buf_bytes > 0 ? buf_bytes : 16));
+    FIT_SP(rocsparse_spgemm(sp, rocsparse_operation_none, rocsparse_operation_none, &alpha, dA, dB, nullptr, dD, dC, rocsparse_datatype_f64_r,
+                            rocsparse_spgemm_alg_default, rocsparse_spgemm_stage_nnz, &buf_bytes, buf));
+    int64_t rows = 0, cols = 0, w_nnz = 0;
+    FIT_SP(rocsparse_spmat_get_size(dC, &rows, &cols, &w_nnz));
+    const int64_t wz1 = w_nnz > 0 ? w_nnz : 1;
+    FIT_HIP(hipMalloc((void **)&c_idx, sizeof(int32_t) * wz1));
+    FIT_HIP(hipMalloc((void **)&c_val, sizeof(double) * wz1));
+    FIT_SP(rocsparse_csr_set_pointers(dC, c_ptr, c_idx, c_val));
+    FIT_SP(rocsparse_spgemm(sp, rocsparse_operation_none, rocsparse_operation_none, &alpha, dA, dB, nullptr, dD, dC, rocsparse_datatype_f64_r,
+                            rocsparse_spgemm_alg_default, rocsparse_spgemm_stage_compute, &buf_bytes, buf));
+    FIT_HIP(hipDeviceSynchronize());
+    // columns ascending inside every row: one radix sort of (row, column) keys carrying the values
+    FIT_HIP(hipMalloc((void **)&k_in, sizeof(uint64_t) * wz1));
+    FIT_HIP(hipMalloc((void **)&k_out, sizeof(uint64_t) * wz1));
+    FIT_HIP(hipMalloc((void **)&c_val2, sizeof(double) * wz1));
+    FIT_HIP(hipMalloc((void **)&out->w_idx, sizeof(int32_t) * wz1));
+    FIT_HIP(hipMalloc((void **)&out->w_val, sizeof(float) * wz1));
+    if (w_nnz > 0) {
+        hipLaunchKernelGGL(rp3_keys_kernel, dim3((unsigned)n_items), dim3(256), 0, 0, c_ptr, c_idx, n_items, k_in);
+        int row_bits = 1;
+        while (((int64_t)1 << row_bits) < n_items) ++row_bits;
+        size_t sort_bytes = 0;
+        FIT_HIP(rocprim::radix_sort_pairs(nullptr, sort_bytes, k_in, k_out, c_val, c_val2, (size_t)w_nnz, 0, 32 + row_bits, 0));
+        (void)hipFree(tmp); tmp = nullptr;
+        FIT_HIP(hipMalloc(&tmp, sort_bytes > 0 ? sort_bytes : 16));
+        FIT_HIP(rocprim::radix_sort_pairs(tmp, sort_bytes, k_in, k_out, c_val, c_val2, (size_t)w_nnz, 0, 32 + row_bits, 0));
+        hipLaunchKernelGGL(rp3_unpack_kernel, dim3((unsigned)((w_nnz + 255) / 256)), dim3(256), 0, 0, k_out, c_val2, w_nnz, out->w_idx,
+                           out->w_val);
+    }
+    FIT_HIP(hipGetLastError());
+    FIT_HIP(hipDeviceSynchronize());
+    out->w_ptr = c_ptr;
+    out->w_nnz = w_nnz;
+    cleanup(true);
+    return 0;
+#undef FIT_HIP
+#undef FIT_SP
+}
+
+void rp3_free(Rp3Arrays *a)
+{
+    (void)hipFree(a->w_ptr); (void)hipFree(a->w_idx); (void)hipFree(a->w_val); (void)hipFree(a->p_val32); (void)hipFree(a->deg);
+    memset(a, 0, sizeof(*a));
+}
+
+void rp3_release(void **rocsparse_cache)
+{
+    if (*rocsparse_cache) { rocsparse_destroy_handle((rocsparse_handle)*rocsparse_cache); *rocsparse_cache = nullptr; }
 }
 
 }  // namespace ifr

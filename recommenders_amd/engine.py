@@ -156,6 +156,22 @@ class HipScorer:
         del kp, ki, kv
         return B
 
+    def fit_rp3beta(self, indptr, indices, n_items, beta):
+        """RP3-beta item-item model on the device from the binarised train pattern A (CSR): W = P_iu . P_ui becomes
+        the CSR item matrix, P_ui the histories, 1/deg^beta the column scale.  Returns the number of entries of W."""
+        pp, kp = self._any_ptr(indptr, np.int64)
+        pi, ki = self._any_ptr(indices, np.int32)
+        w_nnz = ctypes.c_int64(0)
+        n_users = len(indptr) - 1
+        self._check(self._lib.ifr_fit_rp3beta(self._h, pp, pi, n_users, int(n_items), len(indices), float(beta),
+                                              ctypes.byref(w_nnz)))
+        self.n_items, self.k, self.n_users = int(n_items), 0, 2 ** 31 - 1      # users past the last row: no history
+        self.catalogue_items = self.n_items
+        self.item_model = "csr"
+        self.has_exclusions = False
+        del kp, ki
+        return int(w_nnz.value)
+
     def set_item_matrix_csr(self, indptr, indices, values, n_items, col_scale=None):
         """Item-item model with a sparse M (CSR rows, strictly ascending columns)."""
         pp, kp = self._any_ptr(indptr, np.int64)

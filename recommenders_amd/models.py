@@ -422,14 +422,18 @@ class RP3_Beta(ItemItemScoringMixin, RecommenderBase):
     """cornac.models.RP3_Beta scoring (cornac/models/rp3_beta/recom_rp3beta.py:99-131,
     graph_recommender.py:87-117): s = P3[u, items] / deg(item)^beta, evaluated in item-item form
     s = (P_ui[u, :] . W) * deg^-beta with W = P_iu . P_ui, so the (U+I)^2 cube P3 is never built.
-    `fit` builds P_ui, W and the degrees from the binarised train matrix (rating > 0, :76) with
-    SciPy on the host: the model build step, outside the hot path.
+    `fit` builds P_ui, W and the degrees from the binarised train matrix (rating > 0, :76): build="device"
+    through ifr_fit_rp3beta (counting-sort transpose + rocSPARSE SpGEMM, W stays on the device), build="host"
+    (and any dense item matrix) with SciPy like the reference.
     item_matrix: "csr" | "dense" | "auto" (dense below 8192 items)."""
 
-    def __init__(self, beta=0.7, name="RP3_beta", trainable=True, verbose=False, item_matrix="auto", **kwargs):
+    def __init__(self, beta=0.7, name="RP3_beta", trainable=True, verbose=False, item_matrix="auto", build="device", **kwargs):
         RecommenderBase.__init__(self, name=name, trainable=trainable, verbose=verbose)
         self.beta = beta
         self.item_matrix = item_matrix
+        if build not in ("device", "host"):
+            raise ValueError("build must be 'device' or 'host'")
+        self.build = build
         self.P_ui = self.W = self.item_degrees = None
 
     def fit(self, train_set, val_set=None):
@@ -438,6 +442,23 @@ class RP3_Beta(ItemItemScoringMixin, RecommenderBase):
         A = sp.csr_matrix(train_set.csr_matrix, dtype=np.float64, copy=True)   # never write into the data set
         A.data[:] = (A.data > 0).astype(np.float64)                  # recom_rp3beta.py:73-93
         A.eliminate_zeros()
+        A.sum_duplicates()
+        A.sort_indices()
+        self.hip_invalidate()
+        self.item_degrees = A.getnnz(axis=0).astype(np.int64)        # :67
+        if self.build == "device" and self.item_matrix != "dense":
+            # W = P_iu . P_ui, P_ui and 1/deg^beta are built and installed by ifr_fit_rp3beta; W stays on the device
+            from .engine import HipScorer
+            eng = HipScorer(self.hip_device)
+            try:
+                self.w_nnz = eng.fit_rp3beta(A.indptr.astype(np.int64), A.indices.astype(np.int32), A.shape[1], self.beta)
+            except Exception:
+                eng.close()
+                raise
+            self.P_ui = self.W = None
+            self._hip_zero_row = max(int(self.total_users or 0), A.shape[0])
+            self._hip = eng
+            return self
         du = np.asarray(A.sum(axis=1)).ravel()
         di = np.asarray(A.sum(axis=0)).ravel()
         du[du == 0] = 0.0001                                          # graph_recommender.py:54
@@ -446,11 +467,12 @@ class RP3_Beta(ItemItemScoringMixin, RecommenderBase):
         P_iu = (sp.diags(1.0 / di) @ A.T).tocsr()
         self.W = (P_iu @ self.P_ui).tocsr()
         self.W.sort_indices()
-        self.item_degrees = A.getnnz(axis=0).astype(np.int64)        # :67
-        self.hip_invalidate()
         return self
 
     def _hip_item_model(self):
+        if self.W is None:
+            raise RuntimeError("RP3_Beta: W was built on the device and went with the engine that hip_invalidate() "
+                               "closed -- call fit() again (or fit with build='host')")
         # the reference keeps the degrees in an int array, so its 0.0001 guard stores 0 and a
         # zero-degree item scores 0 * inf = nan (graph_recommender.py:107-115); same here
         with np.errstate(divide="ignore"):

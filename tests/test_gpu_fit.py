@@ -1,4 +1,5 @@
-"""GPU tests of the model build entry point ifr_fit_ease through the C ABI.
+"""GPU tests of the model build entry points ifr_fit_ease / ifr_fit_rp3beta
+through the C ABI.
 
 Bars: B against the reference's own EASE.fit output (tests/golden/toy_all_models.npz, made by
 tests/golden/make_golden.py) and against the reference's closed form restated in NumPy fp64
@@ -8,6 +9,7 @@ import numpy as np
 import pytest
 import scipy.sparse as sp
 
+from oracle import oracle as orc
 from test_oracle import _csr
 
 pytestmark = pytest.mark.gpu
@@ -81,3 +83,51 @@ def test_ease_fit_rejects_bad_input(torch):
     with pytest.raises(RuntimeError, match="non-finite"):
         sc.fit_ease(ptr, np.array([1, 3], np.int32), np.array([1.0, np.inf], np.float32), 5, 10.0)
     sc.close()
+
+
+def test_rp3_fit_installs_w_histories_and_penalty(torch):
+    """ifr_fit_rp3beta against the host restatement of graph_recommender.py:24-55 (oracle.rp3_model_arrays, pinned
+    by the reference's RP3 scores in test_oracle.py): the installed CSR matrix read back through one-item
+    histories, and the rankings of the installed model against the same model uploaded from the host arrays."""
+    from recommenders_amd import HipScorer, synth
+    rng = np.random.default_rng(9)
+    n_users, n_items = 2500, 1800
+    ptr, idx, _, _ = synth.interactions(rng, n_users, n_items - 100, 20, lo=0)     # the last 100 items: no user
+    A = sp.csr_matrix((np.ones(len(idx)), idx, ptr), shape=(n_users, n_items))
+    assert (A.getnnz(axis=0) == 0).any()                      # items nobody touched: col_scale = inf
+    beta = 0.7
+    P32, W32, pen = orc.rp3_model_arrays(A, beta)
+    dev = HipScorer(0)
+    w_nnz = dev.fit_rp3beta(ptr, idx, n_items, beta)
+    assert w_nnz == W32.nnz
+    users = np.arange(n_users + 1, dtype=np.int32)            # the last one has no history row
+    host = HipScorer(0)
+    host.set_item_matrix_csr(W32.indptr.astype(np.int64), W32.indices, W32.data, n_items, pen)
+    host.set_history_csr(P32.indptr.astype(np.int64), P32.indices, P32.data)
+    for s_ in (dev, host):
+        s_.set_exclusion_csr(ptr, idx)
+    a_ids, a_sc = dev.rank_topk(users, 10)
+    b_ids, b_sc = host.rank_topk(users, 10)
+    a_ids, b_ids, a_sc, b_sc = a_ids.cpu().numpy(), b_ids.cpu().numpy(), a_sc.cpu().numpy(), b_sc.cpu().numpy()
+    np.testing.assert_allclose(a_sc, b_sc, rtol=1e-6, atol=0)
+    assert (a_ids == b_ids).all(axis=1).mean() > 0.99        # fp64 summation order may flip a last bit of W
+    # W itself: rows of the installed matrix (col_scale folded in) through one-item histories
+    items = np.array([0, 5, 900, n_items - 1], np.int32)
+    dev.set_history_csr(np.arange(len(items) + 1, dtype=np.int64), items, np.ones(len(items), np.float32))
+    rows = dev.score_dense(np.arange(len(items), dtype=np.int32)).cpu().numpy()[:, :n_items]
+    with np.errstate(invalid="ignore"):
+        want = (W32[items].toarray() * pen[None, :]).astype(np.float32)
+    np.testing.assert_allclose(rows, want, rtol=3e-7, atol=0, equal_nan=True)
+    dev.close(); host.close()
+
+
+def test_rp3_facade_device_build_matches_host_build(torch, toy):
+    from recommenders_amd.data import Dataset
+    from recommenders_amd.models import RP3_Beta
+    d = toy
+    train_set = Dataset.from_csr(_csr(d, "train"))
+    dev = RP3_Beta(beta=float(d["rp3_beta"]), item_matrix="csr", build="device").fit(train_set)
+    host = RP3_Beta(beta=float(d["rp3_beta"]), item_matrix="csr", build="host").fit(train_set)
+    assert dev.W is None and dev.w_nnz == host.W.nnz
+    for u in range(0, train_set.num_users, 7):
+        np.testing.assert_allclose(dev.score(u), host.score(u), rtol=1e-6, atol=0, equal_nan=True)

@@ -213,7 +213,7 @@ def test_rp3_fit_builds_item_item_form_and_leaves_the_dataset_alone(toy):
     d = toy
     train_set, _, _ = _datasets(d)
     before = train_set.csr_matrix.data.copy()
-    m = RP3_Beta(beta=float(d["rp3_beta"])).fit(train_set)
+    m = RP3_Beta(beta=float(d["rp3_beta"]), build="host").fit(train_set)
     np.testing.assert_array_equal(train_set.csr_matrix.data, before)
     A_bin = sp.csr_matrix((_csr(d, "train") > 0).astype(np.float64))
     P32, W32, pen = orc.rp3_model_arrays(A_bin, float(d["rp3_beta"]))
