@@ -331,7 +331,7 @@ static int copy_csr(ifr_handle h, const int64_t *indptr, const int32_t *indices,
     for (int64_t r = 0; r < n_rows; ++r)
         if ((*host_ptr)[r + 1] < (*host_ptr)[r]) return fail(h, IFR_ERR_ARG, "CSR: indptr not monotone");
     IFR_HIP(h, hipMalloc((void **)d_ptr, sizeof(int64_t) * (n_rows + 1)));
-    IFR_HIP(h, hipMalloc((void **)d_idx, sizeof(int32_t) * std::max<int64_t>(nnz, 1)));
+    IFR_HIP(h, hipMalloc((void **)d_idx, sizeof(int32_t) * (nnz + ifr::item_csr_pad())));     // padded: see item_csr_pad
     IFR_HIP(h, hipMemcpy(*d_ptr, host_ptr->data(), sizeof(int64_t) * (n_rows + 1), hipMemcpyHostToDevice));
     if (nnz > 0) IFR_HIP(h, hipMemcpy(*d_idx, indices, sizeof(int32_t) * nnz, hipMemcpyDefault));
     return IFR_OK;
@@ -487,7 +487,7 @@ int ifr_set_item_matrix_csr(ifr_handle h, const int64_t *indptr, const int32_t *
     int *d_flags = nullptr;                      // [0] = validation flags, [1] = max |value| bits
     auto cleanup = [&]() { dfree(d_ptr); dfree(d_flags); };
     if (hipMalloc((void **)&d_flags, 2 * sizeof(int)) != hipSuccess || hipMemset(d_flags, 0, 2 * sizeof(int)) != hipSuccess ||
-        hipMalloc((void **)&h->ii_val, sizeof(float) * std::max<int64_t>(nnz, 1)) != hipSuccess ||
+        hipMalloc((void **)&h->ii_val, sizeof(float) * (nnz + ifr::item_csr_pad())) != hipSuccess ||
         hipMalloc((void **)&h->ii_cptr, sizeof(int64_t) * n_items * (n_chunks + 1)) != hipSuccess) {
         cleanup(); clear_item_model(h);
         return fail(h, IFR_ERR_NOMEM, "ifr_set_item_matrix_csr: device allocation failed");

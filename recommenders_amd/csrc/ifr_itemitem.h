@@ -39,6 +39,7 @@ int launch_item_item(const ItemItemParams &p, bool sparse, bool topk, hipStream_
 int launch_item_sparse_topk(const ItemItemParams &p, int32_t *out_ids, float *out_scores, hipStream_t stream);
 int item_sparse_pass_capacity();
 int item_sparse_max_chunks();
+int item_csr_pad();             // entries the CSR index / value arrays must be allocated past nnz
 int item_item_chunk(bool sparse);
 int item_item_pass();
 int launch_validate_csr(const int64_t *ptr, const int32_t *idx, int64_t n_rows, int n_cols, int need_sorted, int *bad,

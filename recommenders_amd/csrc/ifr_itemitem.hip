@@ -34,6 +34,7 @@ constexpr int II_NONE = 0x7fffffff;
 constexpr int II_DENSE_PASSES = 8;            // dense M: 8192 items per workgroup
 constexpr int II_SPARSE_PASSES = 4;           // sparse M: 4096 items per workgroup (32 KB of int64 LDS)
 constexpr int II_GROUP = 16;                  // lanes that share one sparse row segment
+constexpr int II_CSR_PAD = 64;                // entries allocated past the end of the CSR arrays (over-read, never used)
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -285,17 +286,18 @@ __global__ __launch_bounds__(II_BLOCK, 3) void item_item_kernel(ItemItemParams p
 //                the touched columns per chunk and takes the K lowest untouched item ids.
 // ------------------------------------------------------------------------------------
 constexpr int SP_CHUNK = II_SPARSE_PASSES * II_PASS;   // 4096 columns: granularity of cptr
-constexpr int SP_BLOCK = 512;                           // threads per user: two workgroups (4 waves/SIMD) per CU
-constexpr int SP_SPT = 11;                              // hash slots per thread
-constexpr int SP_SLOTS = SP_BLOCK * SP_SPT;             // 5632 slots
-constexpr int SP_CAP = SP_SLOTS * 5 / 8;                // entries per hash pass (load <= 0.625; flat optimum 0.5-0.65)
+constexpr int SP_BLOCK = 512;                           // threads per user: three workgroups (6 waves/SIMD, <= 85 VGPRs) per CU
+constexpr int SP_SPT = 7;                               // hash slots per thread
+constexpr int SP_SLOTS = SP_BLOCK * SP_SPT;             // 3584 slots (43 KB): the kernel is latency bound, occupancy beats table size
+constexpr int SP_CAP = SP_SLOTS * 11 / 16;              // entries per hash pass (load <= 0.69; measured optimum 0.62-0.75)
 constexpr int SP_RAW = SP_SLOTS * 3 / 2;                // 64-bit words: values, then 32-bit keys
-constexpr int SP_REG = SP_SPT > SP_CHUNK / SP_BLOCK ? SP_SPT : SP_CHUNK / SP_BLOCK;
+constexpr int SP_DPT = (SP_CHUNK + SP_BLOCK - 1) / SP_BLOCK;   // dense pass: accumulators per thread
+constexpr int SP_REG = SP_SPT > SP_DPT ? SP_SPT : SP_DPT;
 constexpr int SP_HIST = 128;                            // history rows staged per round
 constexpr int SP_EXCAP = 256;                           // exclusion row entries kept in LDS
 constexpr int SP_MAXCH = 512;                           // item chunks (catalogue <= 2 097 152 items)
 constexpr int SP_NG = SP_BLOCK / II_GROUP;
-constexpr int SP_ZC = SP_CHUNK / SP_BLOCK;               // columns per thread in the zero sweep              // 16-lane groups per workgroup
+constexpr int SP_ZC = (SP_CHUNK + SP_BLOCK - 1) / SP_BLOCK;               // columns per thread in the zero sweep              // 16-lane groups per workgroup
 constexpr uint32_t SP_FLAG = 0x80000000u;               // key flag: excluded column
 static_assert(SP_RAW >= SP_CHUNK + 2 * (SP_CHUNK / 64) + 64, "dense pass accumulators + bitmaps must fit the table");
 
@@ -342,7 +344,7 @@ __device__ __forceinline__ int sp_row_sum(int v)
 constexpr size_t SP_LDS_BYTES = (size_t)SP_RAW * 8 + (SP_MAXCH + 1) * 8 + 2 * SP_HIST * 8 + 32 * 8 + 2 * SP_HIST * 4 +
                                 SP_EXCAP * 4 + (SP_BLOCK / 64) * 4 + 8;
 
-__global__ __launch_bounds__(SP_BLOCK, 4) void item_sparse_topk_kernel(ItemItemParams p, int32_t *out_ids,
+__global__ __launch_bounds__(SP_BLOCK, 6) void item_sparse_topk_kernel(ItemItemParams p, int32_t *out_ids,
                                                                        float *out_scores)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char sp_lds[];   // > 64 KB: dynamic
@@ -428,30 +430,23 @@ __global__ __launch_bounds__(SP_BLOCK, 4) void item_sparse_topk_kernel(ItemItemP
         for (int e = g / gpr; e < m; e += SP_NG / gpr) {
             if (gpr > 1 && g >= gpr * m) break;                   // groups left over
             const double x = ldexp((double)hx[e], p.fx_shift);
-            const int64_t q1 = s1[e];
-            int64_t q = s0[e] + (g % gpr) * (4 * II_GROUP) + l;
-            int c[4], cn[4];
-            float w[4], wn[4];
-            auto load = [&](int64_t qb, int (&ci)[4], float (&wi)[4]) {
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const int64_t qq = qb + t * II_GROUP;
-                    const int64_t qc = qq < q1 ? qq : q1 - 1;
-                    ci[t] = p.m_idx[qc];
-                    wi[t] = p.m_val[qc];
-                }
-            };
-            if (q < q1) load(q, c, w);
-            while (q < q1) {
-                const int64_t qn = q + step;
-                if (qn < q1) load(qn, cn, wn);
+            const int64_t q0 = s0[e] + (g % gpr) * (4 * II_GROUP) + l;
+            // entries left from this lane's first one; reads run up to 63 entries past the segment (the
+            // arrays are padded by II_CSR_PAD entries at set time), such entries arrive with ok = false
+            int rem = (int)min(s1[e] - q0, (int64_t)0x7fffffff);
+            const int32_t *ip = p.m_idx + q0;
+            const float *vp = p.m_val + q0;
+            for (; rem > 0; rem -= step, ip += step, vp += step) {
+                int c[4];
+                float w[4];
                 bool ok[4];
 #pragma unroll
-                for (int t = 0; t < 4; ++t) ok[t] = q + t * II_GROUP < q1;
+                for (int t = 0; t < 4; ++t) {
+                    c[t] = ip[t * II_GROUP];
+                    w[t] = vp[t * II_GROUP];
+                    ok[t] = t * II_GROUP < rem;
+                }
                 fn(c, w, ok, x);
-#pragma unroll
-                for (int t = 0; t < 4; ++t) { c[t] = cn[t]; w[t] = wn[t]; }
-                q = qn;
             }
         }
     };
@@ -614,8 +609,8 @@ __global__ __launch_bounds__(SP_BLOCK, 4) void item_sparse_topk_kernel(ItemItemP
             for_exclusions(colA, colB, [&](int col) { atomicOr(&xbm[(col - colA) >> 5], 1u << (col & 31)); });
             walk(ca, cb, [&](const int (&c)[4], const float (&w)[4], const bool (&ok)[4], double x) {
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {                                   // a clamped duplicate adds 0 / ors 0
-                    const int lc = c[t] - colA;
+                for (int t = 0; t < 4; ++t) {                                   // an entry past the segment adds 0 / ors 0 at column 0
+                    const int lc = ok[t] ? c[t] - colA : 0;
                     atomicAdd(&raw[lc], ok[t] ? fixed(w[t], x) : 0ull);
                     atomicOr(&tbm[lc >> 5], ok[t] ? 1u << (lc & 31) : 0u);
                 }
@@ -624,8 +619,9 @@ __global__ __launch_bounds__(SP_BLOCK, 4) void item_sparse_topk_kernel(ItemItemP
 #pragma unroll
             for (int v = 0; v < SP_REG; ++v) {
                 kreg[v] = 0ull;
-                if (v >= SP_CHUNK / SP_BLOCK) continue;
+                if (v >= SP_DPT) continue;
                 const int lc = tid + v * SP_BLOCK;
+                if (lc >= SP_CHUNK) continue;
                 const uint32_t bit = 1u << (lc & 31);
                 if (!(tbm[lc >> 5] & bit)) continue;
                 const long long a = (long long)raw[lc];
@@ -704,7 +700,7 @@ __global__ __launch_bounds__(SP_BLOCK, 4) void item_sparse_topk_kernel(ItemItemP
             for (int v = 0; v < SP_ZC; ++v) {
                 const int lc = SP_ZC * tid + v;
                 const int col = c0 + lc;
-                bool ok = col < p.n_items && !((zbm[lc >> 5] >> (lc & 31)) & 1u);
+                bool ok = lc < SP_CHUNK && col < p.n_items && !((zbm[min(lc, SP_CHUNK - 1) >> 5] >> (lc & 31)) & 1u);
                 if (ok && p.pen != nullptr) { const float z = 0.0f * p.pen[col]; ok = z == z; }
                 if (ok) ok = sp_key(0.0f, col) > tau && !excluded(col);
                 if (ok) { okbits |= 1u << v; ++mine; }
@@ -770,6 +766,7 @@ int launch_item_item(const ItemItemParams &p, bool sparse, bool topk, hipStream_
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
+int item_csr_pad() { return II_CSR_PAD; }
 int item_item_chunk(bool sparse) { return (sparse ? II_SPARSE_PASSES : II_DENSE_PASSES) * II_PASS; }
 int item_item_pass() { return II_PASS; }
 
