@@ -431,8 +431,8 @@ __global__ __launch_bounds__(SP_BLOCK, 6) void item_sparse_topk_kernel(ItemItemP
             if (gpr > 1 && g >= gpr * m) break;                   // groups left over
             const double x = ldexp((double)hx[e], p.fx_shift);
             const int64_t q0 = s0[e] + (g % gpr) * (4 * II_GROUP) + l;
-            // entries left from this lane's first one; reads run up to 63 entries past the segment (the
-            // arrays are padded by II_CSR_PAD entries at set time), such entries arrive with ok = false
+            // entries left from this lane's first one; strides past the segment re-read its last entry of this
+            // lane and arrive with ok = false
             int rem = (int)min(s1[e] - q0, (int64_t)0x7fffffff);
             const int32_t *ip = p.m_idx + q0;
             const float *vp = p.m_val + q0;
@@ -442,9 +442,10 @@ __global__ __launch_bounds__(SP_BLOCK, 6) void item_sparse_topk_kernel(ItemItemP
                 bool ok[4];
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
-                    c[t] = ip[t * II_GROUP];
-                    w[t] = vp[t * II_GROUP];
                     ok[t] = t * II_GROUP < rem;
+                    const int o = min(t * II_GROUP, rem - 1);     // stay inside the segment's cache lines
+                    c[t] = ip[o];
+                    w[t] = vp[o];
                 }
                 fn(c, w, ok, x);
             }
