@@ -154,6 +154,22 @@ def score_ease(X_csr, B, u):
     return np.asarray(X_csr[u, :].dot(B)).ravel()
 
 
+def ease_closed_form(X_csr, lamb, posB):
+    """EASE.fit, cornac/models/ease/recom_ease.py:75-95: G = X^T X + lamb I, P = G^-1,
+    B = P / (-diag P) column-wise, diag B = 0, posB: B[B < 0] = 0.  fp64, dense [I, I]."""
+    import scipy.sparse as sp
+    X = sp.csr_matrix(X_csr, dtype=np.float64)
+    G = X.T.dot(X).toarray()
+    di = np.diag_indices(G.shape[0])
+    G[di] = G.diagonal() + lamb
+    P = np.linalg.inv(G)
+    B = P / (-np.diag(P))
+    B[di] = 0.0
+    if posB:
+        B[B < 0] = 0
+    return B
+
+
 def rp3_item_item(A_csr):
     """graph_recommender.py:24-55, 83-84 written in item-item form.
 

@@ -25,6 +25,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
+#include <algorithm>
 
 #include "ifr_fit.h"
 
@@ -70,8 +71,8 @@ __global__ void take_diag_kernel(const double *S, int64_t n, double *d)
 // caller's copy) and M [n][ldm] receives the fp32 matrix
 __global__ __launch_bounds__(FIT_BLOCK) void ease_scale_kernel(double *S, const double *d, int64_t n, int posB, float *M, int64_t ldm)
 {
-    const int64_t j = blockIdx.y;
-    const int64_t c = (int64_t)blockIdx.x * FIT_BLOCK + threadIdx.x;
+    const int64_t j = blockIdx.x;                        // grid.y is limited to 65535: rows go on x
+    const int64_t c = (int64_t)blockIdx.y * FIT_BLOCK + threadIdx.x;
     if (c >= n) return;
     double v = S[j * n + c] / (-d[c]);
     if (j == c) v = 0.0;
@@ -90,7 +91,9 @@ int ease_build(const int64_t *d_ptr, const int32_t *d_idx, const float *d_val, i
                int posB, float *M, int64_t ldm, double *B_host, void **rocblas_cache, char *err, size_t errlen)
 {
     const int64_t n = n_items;
-    if (n_users > 0x7fffffff || n > 65535LL * FIT_BLOCK) return fit_fail(err, errlen, "too many users or items for one launch", 0);
+    // HIP: grid.x * block.x < 2^32, grid.y <= 65535
+    if (n_users > (int64_t)0xffffffffu / FIT_BLOCK || n > (int64_t)0xffffffffu / FIT_BLOCK)
+        return fit_fail(err, errlen, "too many users or items for one launch", 0);
     double *G = nullptr, *S = nullptr, *diag = nullptr;
     int64_t *info = nullptr;
     auto cleanup = [&]() { (void)hipFree(G); (void)hipFree(S); (void)hipFree(diag); (void)hipFree(info); };
@@ -126,7 +129,7 @@ int ease_build(const int64_t *d_ptr, const int32_t *d_idx, const float *d_val, i
     st = rocsolver_dpotrs_64(rb, rocblas_fill_upper, n, n, G, n, S, n);          // S = G^-1 (symmetric: either storage order)
     if (st != rocblas_status_success) { cleanup(); return fit_fail(err, errlen, "triangular solves failed", (int)st); }
     hipLaunchKernelGGL(take_diag_kernel, dim3(nb), dim3(256), 0, 0, S, n, diag);
-    hipLaunchKernelGGL(ease_scale_kernel, dim3(nb, (unsigned)n), dim3(FIT_BLOCK), 0, 0, S, diag, n, posB, M, ldm);
+    hipLaunchKernelGGL(ease_scale_kernel, dim3((unsigned)n, nb), dim3(FIT_BLOCK), 0, 0, S, diag, n, posB, M, ldm);
     e = hipGetLastError();
     if (e == hipSuccess) e = hipDeviceSynchronize();
     if (e == hipSuccess && B_host) e = hipMemcpy(B_host, S, bytes, hipMemcpyDeviceToHost);
@@ -143,8 +146,8 @@ void ease_release(void **rocblas_cache)
 // ------------------------------------------------------------------------------------ RP3-beta
 __global__ void column_count_kernel(const int32_t *idx, int64_t nnz, unsigned long long *cnt)
 {
-    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e < nnz) atomicAdd(&cnt[idx[e]], 1ull);
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < nnz; e += (int64_t)gridDim.x * blockDim.x)
+        atomicAdd(&cnt[idx[e]], 1ull);
 }
 
 // one thread per user row: P_ui values (1 / deg(u), fp64 and fp32) and the transposed entries
@@ -174,8 +177,10 @@ __global__ void rp3_keys_kernel(const int64_t *ptr, const int32_t *idx, int64_t 
 
 __global__ void rp3_unpack_kernel(const uint64_t *keys, const double *val, int64_t nnz, int32_t *idx, float *val32)
 {
-    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e < nnz) { idx[e] = (int32_t)(uint32_t)keys[e]; val32[e] = (float)val[e]; }
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < nnz; e += (int64_t)gridDim.x * blockDim.x) {
+        idx[e] = (int32_t)(uint32_t)keys[e];
+        val32[e] = (float)val[e];
+    }
 }
 
 struct to_i64 {
@@ -189,7 +194,8 @@ int rp3_build(const int64_t *a_ptr, const int32_t *a_idx, int64_t n_users, int64
         if (err && errlen) snprintf(err, errlen, "ifr_fit_rp3beta: %s (%d)", what, code);
         return -1;
     };
-    if (n_users >= 0x7fffffff || nnz >= ((int64_t)1 << 40)) return fail("too many users or interactions", 0);
+    if (n_users > (int64_t)0xffffffffu / 256 || n_items > (int64_t)0xffffffffu / 256 || nnz >= ((int64_t)1 << 40))
+        return fail("too many users, items or interactions", 0);
     memset(out, 0, sizeof(*out));
     unsigned long long *cnt = nullptr, *cursor = nullptr;
     int64_t *t_ptr = nullptr, *c_ptr = nullptr, *z_ptr = nullptr;
@@ -228,7 +234,7 @@ int rp3_build(const int64_t *a_ptr, const int32_t *a_idx, int64_t n_users, int64
     FIT_HIP(hipMemset(cnt, 0, sizeof(unsigned long long) * (n_items + 1)));
     FIT_HIP(hipMemset(cursor, 0, sizeof(unsigned long long) * n_items));
     // item degrees -> row pointers of A^T (exclusive scan)
-    if (nnz > 0) hipLaunchKernelGGL(column_count_kernel, dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, 0, a_idx, nnz, cnt);
+    if (nnz > 0) hipLaunchKernelGGL(column_count_kernel, dim3((unsigned)std::min<int64_t>((nnz + 255) / 256, 1 << 20)), dim3(256), 0, 0, a_idx, nnz, cnt);
     size_t tmp_bytes = 0;
     auto cnt_in = rocprim::make_transform_iterator(cnt, to_i64());
     FIT_HIP(rocprim::exclusive_scan(nullptr, tmp_bytes, cnt_in, t_ptr, (int64_t)0, (size_t)(n_items + 1), rocprim::plus<int64_t>(), 0));
@@ -286,7 +292,7 @@ int rp3_build(const int64_t *a_ptr, const int32_t *a_idx, int64_t n_users, int64
         (void)hipFree(tmp); tmp = nullptr;
         FIT_HIP(hipMalloc(&tmp, sort_bytes > 0 ? sort_bytes : 16));
         FIT_HIP(rocprim::radix_sort_pairs(tmp, sort_bytes, k_in, k_out, c_val, c_val2, (size_t)w_nnz, 0, 32 + row_bits, 0));
-        hipLaunchKernelGGL(rp3_unpack_kernel, dim3((unsigned)((w_nnz + 255) / 256)), dim3(256), 0, 0, k_out, c_val2, w_nnz, out->w_idx,
+        hipLaunchKernelGGL(rp3_unpack_kernel, dim3((unsigned)std::min<int64_t>((w_nnz + 255) / 256, 1 << 20)), dim3(256), 0, 0, k_out, c_val2, w_nnz, out->w_idx,
                            out->w_val);
     }
     FIT_HIP(hipGetLastError());

@@ -2,8 +2,8 @@
 through the C ABI.
 
 Bars: B against the reference's own EASE.fit output (tests/golden/toy_all_models.npz, made by
-tests/golden/make_golden.py) and against the reference's closed form restated in NumPy fp64
-(recom_ease.py:78-95): 1e-8 relative to the largest entry (Cholesky here, LU there); the fp32 matrix the
+tests/golden/make_golden.py) and against the oracle's restatement of the closed form
+(oracle.ease_closed_form, recom_ease.py:78-95, pinned by that same B in test_oracle.py): 1e-8 relative to the largest entry (Cholesky here, LU there); the fp32 matrix the
 scoring kernels read is exactly fl32(B)."""
 import numpy as np
 import pytest
@@ -21,18 +21,6 @@ def torch():
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     return torch
-
-
-def _closed_form(X, lamb, posB):
-    G = X.T.dot(X).toarray().astype(np.float64)
-    di = np.diag_indices(G.shape[0])
-    G[di] = G.diagonal() + lamb
-    P = np.linalg.inv(G)
-    B = P / (-np.diag(P))
-    B[di] = 0.0
-    if posB:
-        B[B < 0] = 0
-    return B
 
 
 def test_ease_fit_matches_reference_output(torch, toy):
@@ -62,7 +50,7 @@ def test_ease_fit_matches_closed_form_and_installs_fl32_B(torch, posB, ratings):
     X.sort_indices()
     sc = HipScorer(0)
     B = sc.fit_ease(X.indptr.astype(np.int64), X.indices, X.data, n_items, 500.0, posB, want_B=True)
-    ref = _closed_form(X.astype(np.float64), 500.0, posB)
+    ref = orc.ease_closed_form(X, 500.0, posB)
     np.testing.assert_allclose(B, ref, rtol=0, atol=1e-8 * np.abs(ref).max())
     # one-item histories read rows of the installed matrix: exactly fl32(B)
     items = np.array([0, 7, 1024, n_items - 1], np.int32)

@@ -247,6 +247,13 @@ def _close(got, ref, tol):
     assert np.all(np.abs(got[ok] - ref[ok]) <= tol * scale[ok])
 
 
+def test_ease_closed_form_against_reference_fit(toy):
+    """oracle.ease_closed_form against B of the reference's own EASE(lamb=50, posB=True).fit on the toy train set."""
+    d = toy
+    B = orc.ease_closed_form(_csr(d, "train"), 50, True)
+    np.testing.assert_allclose(B, d["ease_B"], rtol=1e-9, atol=1e-12)
+
+
 def test_item_dense_restatement_against_reference_ease(toy):
     """fp32 fma chain in history order (what the HIP dense kernel computes) vs EASE.score of the reference."""
     d = toy
