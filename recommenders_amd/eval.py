@@ -55,6 +55,32 @@ def build_eval_csrs(train_mat, test_mat, val_mat, rating_threshold, n_items, n_r
     return truth, excl, has_pos
 
 
+# Experiment / hyper-parameter search evaluate many models on the same splits (base_method.py:1106-1116,
+# hyperopt.py:151-159): the CSRs above depend only on the splits, so the last few are kept.
+_EVAL_CSR_CACHE = []
+_EVAL_CSR_CACHE_SIZE = 4
+
+
+def _fingerprint(mat):
+    if mat is None:
+        return None
+    m = sp.csr_matrix(mat)
+    return (m.shape, m.nnz, float(m.data.sum()), int(m.indices[::97].sum()), int(m.indptr[::97].sum()))
+
+
+def cached_eval_csrs(train_mat, test_mat, val_mat, rating_threshold, n_items, n_rows):
+    """build_eval_csrs, memoised on the identity of the three matrices plus a cheap content fingerprint
+    (shape, nnz, sum of ratings, strided index checksums), so that in-place edits are noticed."""
+    key = (float(rating_threshold), int(n_items), int(n_rows), _fingerprint(train_mat), _fingerprint(test_mat), _fingerprint(val_mat))
+    for ent in _EVAL_CSR_CACHE:
+        if ent[0] is train_mat and ent[1] is test_mat and ent[2] is val_mat and ent[3] == key:
+            return ent[4]
+    out = build_eval_csrs(train_mat, test_mat, val_mat, rating_threshold, n_items, n_rows)
+    _EVAL_CSR_CACHE.insert(0, (train_mat, test_mat, val_mat, key, out))
+    del _EVAL_CSR_CACHE[_EVAL_CSR_CACHE_SIZE:]
+    return out
+
+
 # --------------------------------------------------------------------------- lazy result caches
 class LazyRankCache(Mapping):
     """Dict-like view that materialises `model.ranked_items[u]` / `item_scores[u]` /
@@ -196,15 +222,18 @@ def ranking_eval(model, metrics, train_set, test_set, val_set=None, rating_thres
     # user's minimum (recommender.py:631-635), i.e. they tie at the bottom and, having the largest
     # indices, rank after every known candidate.
     eng.set_catalogue_items(n_items)
-    test_users = np.unique(np.asarray(test_set.uir_tuple[0]).astype(np.int64))
+    # users with a stored test entry = np.unique(test_set.uir_tuple[0]) (base_method.py:254), read off the CSR rows
+    test_users = np.flatnonzero(np.diff(sp.csr_matrix(test_set.csr_matrix).indptr)).astype(np.int64)
     n_rows = int(test_users.max()) + 1 if len(test_users) else 0
-    truth, excl, has_pos = build_eval_csrs(train_set.csr_matrix, test_set.csr_matrix,
-                                           None if val_set is None else val_set.csr_matrix,
-                                           rating_threshold, n_items, n_rows)
+    truth, excl, has_pos = cached_eval_csrs(train_set.csr_matrix, test_set.csr_matrix,
+                                            None if val_set is None else val_set.csr_matrix,
+                                            rating_threshold, n_items, n_rows)
     # reference quirk kept: users already in the model's caches are NOT re-ranked
     # (base_method.py:166-167), so their earlier candidate set (exclusion rows) stays in force
     prev = getattr(model, "_hip_cache_owner", None)
-    if prev is not None and prev.n_items == n_items and len(prev.users):
+    if prev is not None and prev.excl is excl:
+        pass                                                     # same splits as last time: the rows are identical
+    elif prev is not None and prev.n_items == n_items and len(prev.users):
         reuse = prev.users[prev.users < n_rows]
         if len(reuse):
             keep = np.ones(n_rows, bool)

@@ -260,3 +260,24 @@ def test_append_unknown_items_fills_short_lists():
     excl = sp.csr_matrix(np.array([[0, 0, 0, 0, 0, 0, 1, 0, 0], [0] * 9, [0, 0, 0, 0, 0, 0, 1, 1, 1]], dtype=np.int8))
     out = ifr_eval._append_unknown_items(ids, np.array([0, 1, 2]), excl, 6, 9).numpy()
     np.testing.assert_array_equal(out, [[5, 2, 7, 8], [1, 2, 3, 4], [-1, -1, -1, -1]])
+
+
+def test_eval_csrs_are_memoised_per_split_and_notice_edits():
+    """cached_eval_csrs: the same split objects give the same CSRs back; an in-place rating edit or another
+    threshold rebuilds them."""
+    from recommenders_amd import eval as ev
+    rng = np.random.default_rng(3)
+    tr = sp.random(50, 40, density=0.2, format="csr", random_state=np.random.RandomState(1), data_rvs=lambda n: rng.integers(1, 6, n).astype(float))
+    te = sp.random(50, 40, density=0.1, format="csr", random_state=np.random.RandomState(2), data_rvs=lambda n: rng.integers(1, 6, n).astype(float))
+    a = ev.cached_eval_csrs(tr, te, None, 3.0, 40, 50)
+    b = ev.cached_eval_csrs(tr, te, None, 3.0, 40, 50)
+    assert a[0] is b[0] and a[1] is b[1]
+    ref = ev.build_eval_csrs(tr, te, None, 3.0, 40, 50)
+    assert (a[0] != ref[0]).nnz == 0 and (a[1] != ref[1]).nnz == 0 and (a[2] == ref[2]).all()
+    c = ev.cached_eval_csrs(tr, te, None, 4.0, 40, 50)
+    assert c[0] is not a[0]
+    te.data[0] = 5.0 if te.data[0] != 5.0 else 1.0                      # in-place edit of one rating
+    d = ev.cached_eval_csrs(tr, te, None, 3.0, 40, 50)
+    assert d[0] is not a[0]
+    ref2 = ev.build_eval_csrs(tr, te, None, 3.0, 40, 50)
+    assert (d[0] != ref2[0]).nnz == 0 and (d[1] != ref2[1]).nnz == 0

@@ -1,0 +1,26 @@
+"""Dev: wall time of the facade ranking_eval (the reference's call) at C2 scale next to the raw engine loop."""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, scipy.sparse as sp, torch
+from recommenders_amd import synth, ranking_eval, metrics as M
+from recommenders_amd.data import Dataset
+from recommenders_amd.models import WMF
+nu = int(sys.argv[1]) if len(sys.argv) > 1 else 138493
+w = synth.make("c2_wmf_ml20m", n_users=nu)
+ni = w["n_items"]
+tr = sp.csr_matrix((np.ones(len(w["excl_idx"]), np.float32), w["excl_idx"], w["excl_ptr"]), shape=(nu, ni))
+te = sp.csr_matrix((np.ones(len(w["truth_idx"]), np.float32), w["truth_idx"], w["truth_ptr"]), shape=(nu, ni))
+t = time.perf_counter(); train_set, test_set = Dataset.from_csr(tr), Dataset.from_csr(te); print(f"datasets {time.perf_counter()-t:.2f} s", flush=True)
+model = WMF(k=w["k"], trainable=False, init_params={"U": w["U"], "V": w["V"]}).fit(train_set)
+mets = [M.NDCG(k=10), M.Recall(k=10), M.Precision(k=10)]
+for rep in range(3):
+    model.ranked_items.clear() if hasattr(model.ranked_items, "clear") else None
+    t = time.perf_counter()
+    avg, per_user = ranking_eval(model, mets, train_set, test_set, verbose=False)
+    torch.cuda.synchronize()
+    print(f"ranking_eval run {rep}: {time.perf_counter()-t:.3f} s  {nu/(time.perf_counter()-t)/1e6:.2f} M users/s  avg {avg}", flush=True)
+import cProfile, pstats
+pr = cProfile.Profile(); pr.enable()
+ranking_eval(model, mets, train_set, test_set, verbose=False); torch.cuda.synchronize()
+pr.disable()
+pstats.Stats(pr).sort_stats("cumulative").print_stats(28)
