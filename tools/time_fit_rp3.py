@@ -15,7 +15,10 @@ for rep in range(2):
     torch.cuda.synchronize()
     print(f"fit_rp3beta run {rep}: {time.perf_counter() - t:.2f} s, nnz(W) = {w} ({w / ni:.0f} per row)", flush=True)
 sc.set_exclusion_csr(ptr, idx)
-t = time.perf_counter()
-ids, scores = sc.rank_topk(np.arange(min(nu, 65536), dtype=np.int32), 10)
-torch.cuda.synchronize()
-print(f"rank_topk 65536 users: {time.perf_counter() - t:.3f} s", ids[0].cpu().numpy(), flush=True)
+for dbg in [int(a) for a in (sys.argv[3].split(",") if len(sys.argv) > 3 else ["0"])]:
+    sc.set_option("debug_mode", dbg)
+    for rep in range(2):
+        t = time.perf_counter()
+        ids, scores = sc.rank_topk(np.arange(min(nu, 65536), dtype=np.int32), 10)
+        torch.cuda.synchronize()
+    print(f"debug_mode {dbg}: rank_topk 65536 users: {time.perf_counter() - t:.3f} s", ids[0].cpu().numpy(), flush=True)
