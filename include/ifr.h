@@ -191,6 +191,15 @@ int ifr_rank_full(ifr_handle h, const int32_t *user_ids, int64_t n, const float 
 int ifr_rank_items(ifr_handle h, const float *scores, int64_t n_scores, const int32_t *items, int64_t m,
                    int32_t *out_ids, void *stream);
 
+/* Partial ranking of dense score rows: the K best candidates of every row (K <= 1024) in the order of
+ * ifr_rank_full -- score descending, item index ascending, excluded items skipped, NaN first like
+ * argsort()[::-1] -- without sorting the row.  Recommender.rank(k != -1) does the same with argpartition +
+ * a sort of the head (cornac/models/recommender.py:644-649).  The path for cut-offs beyond the fused
+ * kernel's 32.  scores: dev [n][ld] as written by ifr_score_dense (ld >= catalogue items);
+ * out_ids / out_scores: dev [n][K], rows with fewer than K candidates end in -1 / -inf. */
+int ifr_select_topk(ifr_handle h, const int32_t *user_ids, int64_t n, const float *scores, int64_t ld, int K, int32_t *out_ids,
+                    float *out_scores, void *stream);
+
 /* Items unknown to the model (evaluation with exclude_unknowns = False, cornac/eval_methods/
  * base_method.py:262-279): after ifr_set_option(h, "catalogue_items", N) with N > n_items,
  * ifr_auc_dense and ifr_rank_full treat score rows as N items wide (ld >= N, exclusions < N

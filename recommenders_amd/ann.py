@@ -82,7 +82,7 @@ class HipExactANN(RecommenderBase):
         self._hip_query_is_users = False
         eng.set_exclusion_csr(np.zeros(1, np.int64), np.zeros(0, np.int32))
         rows = np.arange(len(q), dtype=np.int32)
-        if k <= 32:
+        if k <= 1024:                                   # fused kernel up to 32, partial ranking of dense rows beyond
             ids, scores = eng.rank_topk(rows, k)
         else:
             out_i, out_s = [], []

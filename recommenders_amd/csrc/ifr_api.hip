@@ -24,6 +24,9 @@ int launch_auc(const float *scores, int64_t ld, const int32_t *user_ids, int64_t
                double *out, hipStream_t stream);
 int launch_rank_items(const float *scores, int64_t n_scores, const int32_t *items, int64_t m, int32_t *out_ids,
                       void **ws, size_t *ws_bytes, hipStream_t stream);
+int launch_select_topk(const float *scores, int64_t ld, const int32_t *user_ids, int64_t n, int n_items, const int64_t *ex_ptr,
+                       const int32_t *ex_idx, int64_t ex_rows, int K, int32_t *out_ids, float *out_scores, hipStream_t stream);
+int select_topk_max_k();
 int launch_rank_full(const float *scores, int64_t ld, const int32_t *user_ids, int64_t n, int n_items,
                      const int64_t *ex_ptr, const int32_t *ex_idx, int64_t ex_rows,
                      int32_t *out_ids, int32_t *n_cand, void **ws, size_t *ws_bytes, hipStream_t stream);
@@ -895,6 +898,22 @@ int ifr_rank_full(ifr_handle h, const int32_t *user_ids, int64_t n, const float 
     int rc = ifr::launch_rank_full(scores, ld, user_ids, n, (int)cat, h->ex_ptr, h->ex_idx, h->ex_rows, out_ids,
                                    n_cand, &h->ws_sort, &h->ws_sort_bytes, (hipStream_t)stream);
     if (rc) return fail(h, rc, "ifr_rank_full: sort failed");
+    return IFR_OK;
+}
+
+int ifr_select_topk(ifr_handle h, const int32_t *user_ids, int64_t n, const float *scores, int64_t ld, int K, int32_t *out_ids,
+                    float *out_scores, void *stream)
+{
+    if (!h) return IFR_ERR_ARG;
+    if (h->n_items <= 0) return fail(h, IFR_ERR_STATE, "ifr_select_topk: no model set");
+    if (n == 0) return IFR_OK;
+    const int64_t cat = catalogue_items(h);
+    if (!user_ids || !scores || !out_ids || !out_scores || n < 0 || ld < cat) return fail(h, IFR_ERR_ARG, "ifr_select_topk: bad argument");
+    if (K < 1 || K > ifr::select_topk_max_k()) return fail(h, IFR_ERR_ARG, "ifr_select_topk: K must be in [1, 1024]");
+    IFR_HIP(h, hipSetDevice(h->device));
+    if (ifr::launch_select_topk(scores, ld, user_ids, n, (int)cat, h->ex_ptr, h->ex_idx, h->ex_rows, K, out_ids, out_scores,
+                                (hipStream_t)stream))
+        return fail(h, IFR_ERR_HIP, "ifr_select_topk: launch failed (more than 2^24 rows in one call?)");
     return IFR_OK;
 }
 

@@ -242,4 +242,167 @@ int launch_rank_full(const float *scores, int64_t ld, const int32_t *user_ids, i
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
+// ------------------------------------------------------------------------------------
+// Partial ranking of dense score rows: the K best candidates of every row in the order of the full
+// ranking above (score descending, item index ascending; excluded items skipped), without sorting
+// the row -- Recommender.rank(k != -1) does the same with argpartition + a sort of the head
+// (recommender.py:644-649).  One workgroup per row: a three-digit radix select (11 + 11 + 10 bits
+// of the descending-orderable score key, LDS histograms, excluded items subtracted afterwards so the
+// sweeps need no membership test) finds the key of the K-th candidate; one more sweep in item order
+// collects the better ones and, in index order, as many of the equal ones as are still needed;
+// the K keys are sorted in LDS.  HBM/L2-bound: four reads of the row.
+// ------------------------------------------------------------------------------------
+constexpr int SEL_BLOCK = 256;
+constexpr int SEL_MAXK = 1024;
+constexpr int SEL_BINS = 2048;
+
+__global__ __launch_bounds__(SEL_BLOCK) void select_topk_kernel(const float *scores, int64_t ld, const int32_t *user_ids,
+                                                                int n_items, const int64_t *ex_ptr, const int32_t *ex_idx,
+                                                                int64_t ex_rows, int K, int32_t *out_ids, float *out_scores)
+{
+    __shared__ uint32_t hist[SEL_BINS];
+    __shared__ unsigned long long cand[SEL_MAXK];
+    __shared__ uint32_t wsum[SEL_BLOCK / 64];
+    __shared__ uint32_t s_bin, s_below, s_cnt, s_valid_ex;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t i = blockIdx.x;
+    const int u = user_ids[i];
+    const float *row = scores + i * ld;
+    int64_t eb = 0, ee = 0;
+    if (ex_ptr != nullptr && u >= 0 && u < ex_rows) { eb = ex_ptr[u]; ee = ex_ptr[u + 1]; }
+    const int64_t n_ex = ee - eb;
+    auto excluded = [&](int it) -> bool {
+        int64_t lo = 0, hi = n_ex;
+        while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (ex_idx[eb + mid] < it) lo = mid + 1; else hi = mid; }
+        return lo < n_ex && ex_idx[eb + lo] == it;
+    };
+    if (tid == 0) { s_cnt = 0; s_valid_ex = 0; }
+    __syncthreads();
+    {   // candidates of this row: all items minus the valid entries of the exclusion row
+        int c = 0;
+        for (int64_t q = eb + tid; q < ee; q += SEL_BLOCK) { const int it = ex_idx[q]; c += (it >= 0 && it < n_items) ? 1 : 0; }
+        if (c) atomicAdd(&s_valid_ex, (uint32_t)c);
+    }
+    __syncthreads();
+    const int n_cand = n_items - (int)s_valid_ex;
+    const int Ke = min(K, n_cand);
+    if (Ke <= 0) {
+        for (int r = tid; r < K; r += SEL_BLOCK) { out_ids[i * K + r] = -1; out_scores[i * K + r] = -INFINITY; }
+        return;
+    }
+    // ---- the key of the Ke-th candidate, most significant digit first
+    uint32_t prefix = 0;                 // digits fixed so far (in place), mask of the fixed bits
+    uint32_t pmask = 0;
+    uint32_t want = (uint32_t)Ke;        // rank still to find inside the current prefix (1-based)
+    const int shifts[3] = {21, 10, 0};
+    const int widths[3] = {11, 11, 10};
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const int sh = shifts[d];
+        const uint32_t dmask = (1u << widths[d]) - 1u;
+        for (int b = tid; b < SEL_BINS; b += SEL_BLOCK) hist[b] = 0u;
+        __syncthreads();
+        for (int it = tid; it < n_items; it += SEL_BLOCK) {
+            const uint32_t k = desc_key(row[it]);
+            if ((k & pmask) == prefix) atomicAdd(&hist[(k >> sh) & dmask], 1u);
+        }
+        for (int64_t q = eb + tid; q < ee; q += SEL_BLOCK) {
+            const int it = ex_idx[q];
+            if (it >= 0 && it < n_items) {
+                const uint32_t k = desc_key(row[it]);
+                if ((k & pmask) == prefix) atomicSub(&hist[(k >> sh) & dmask], 1u);
+            }
+        }
+        __syncthreads();
+        // first bin whose running count reaches `want`: 8 consecutive bins per thread, block prefix of the sums
+        uint32_t loc[SEL_BINS / SEL_BLOCK];
+        uint32_t mine = 0;
+#pragma unroll
+        for (int v = 0; v < SEL_BINS / SEL_BLOCK; ++v) { loc[v] = hist[tid * (SEL_BINS / SEL_BLOCK) + v]; mine += loc[v]; }
+        uint32_t incl = mine;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { const uint32_t t = __shfl_up(incl, off); if (lane >= off) incl += t; }
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        uint32_t before = incl - mine;
+        for (int w = 0; w < wave; ++w) before += wsum[w];
+        if (before < want && want <= before + mine) {          // exactly one thread
+            uint32_t run = before;
+#pragma unroll
+            for (int v = 0; v < SEL_BINS / SEL_BLOCK; ++v) {
+                if (run < want && want <= run + loc[v]) { s_bin = (uint32_t)(tid * (SEL_BINS / SEL_BLOCK) + v); s_below = run; }
+                run += loc[v];
+            }
+        }
+        __syncthreads();
+        prefix |= s_bin << sh;
+        pmask |= dmask << sh;
+        want -= s_below;
+        __syncthreads();
+    }
+    const uint32_t T = prefix;           // key of the Ke-th candidate; `want` of the candidates with this key are taken
+    // ---- collect in item order: better keys anywhere, equal keys by ascending item index
+    uint32_t taken_eq = 0;
+    for (int base = 0; base < n_items; base += SEL_BLOCK) {
+        const int it = base + tid;
+        bool lt = false, eq = false;
+        uint32_t k = 0;
+        if (it < n_items) {
+            k = desc_key(row[it]);
+            if (k <= T && !excluded(it)) { lt = k < T; eq = k == T; }
+        }
+        if (lt) cand[atomicAdd(&s_cnt, 1u)] = ((unsigned long long)k << 32) | (uint32_t)it;
+        const unsigned long long bal = __ballot(eq);
+        if (lane == 0) wsum[wave] = (uint32_t)__popcll(bal);
+        __syncthreads();
+        uint32_t before = taken_eq, all = 0;
+        for (int w = 0; w < SEL_BLOCK / 64; ++w) { if (w < wave) before += wsum[w]; all += wsum[w]; }
+        before += (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+        if (eq && before < want) cand[atomicAdd(&s_cnt, 1u)] = ((unsigned long long)k << 32) | (uint32_t)it;
+        taken_eq += all;
+        __syncthreads();
+    }
+    // ---- sort the Ke keys ascending (bitonic, padded with the worst key)
+    int np2 = 1;
+    while (np2 < Ke) np2 <<= 1;
+    for (int q = Ke + tid; q < np2; q += SEL_BLOCK) cand[q] = ~0ull;
+    __syncthreads();
+    for (int kk = 2; kk <= np2; kk <<= 1) {
+        for (int j = kk >> 1; j > 0; j >>= 1) {
+            for (int q = tid; q < np2; q += SEL_BLOCK) {
+                const int x = q ^ j;
+                if (x > q) {
+                    const unsigned long long a = cand[q], b = cand[x];
+                    const bool up = (q & kk) == 0;
+                    if ((a > b) == up) { cand[q] = b; cand[x] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (int r = tid; r < K; r += SEL_BLOCK) {
+        int32_t id = -1;
+        float sc = -INFINITY;
+        if (r < Ke) {
+            const unsigned long long c = cand[r];
+            id = (int32_t)(uint32_t)c;
+            const uint32_t b = ~(uint32_t)(c >> 32);                       // ascending-orderable bits
+            sc = __uint_as_float((b & 0x80000000u) ? (b ^ 0x80000000u) : ~b);
+        }
+        out_ids[i * K + r] = id;
+        out_scores[i * K + r] = sc;
+    }
+}
+
+int select_topk_max_k() { return SEL_MAXK; }
+
+int launch_select_topk(const float *scores, int64_t ld, const int32_t *user_ids, int64_t n, int n_items, const int64_t *ex_ptr,
+                       const int32_t *ex_idx, int64_t ex_rows, int K, int32_t *out_ids, float *out_scores, hipStream_t stream)
+{
+    if (n <= 0 || n > (int64_t)0xffffffffu / SEL_BLOCK || K < 1 || K > SEL_MAXK) return -1;
+    hipLaunchKernelGGL(select_topk_kernel, dim3((unsigned)n), dim3(SEL_BLOCK), 0, stream, scores, ld, user_ids, n_items, ex_ptr,
+                       ex_idx, ex_rows, K, out_ids, out_scores);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
 }  // namespace ifr

@@ -12,6 +12,8 @@ from . import _lib
 
 METRICS_PER_K = 6      # ndcg, recall, precision, hit ratio, f1, ncrr (include/ifr.h IFR_METRICS_PER_K)
 METRIC_COLUMNS = ("ndcg", "recall", "precision", "hit", "f1", "ncrr")
+MAX_FUSED_TOPK = 32    # ifr_rank_topk (include/ifr.h IFR_MAX_TOPK)
+MAX_SELECT_TOPK = 1024 # ifr_select_topk
 
 
 class IfrError(RuntimeError):
@@ -218,8 +220,9 @@ class HipScorer:
         del kp, ki
 
     # ------------------------------------------------------------------ compute
-    def rank_topk(self, user_ids, K, out_ids=None, out_scores=None):
-        """Top-K (ids int32 [n,K], scores fp32 [n,K]) for the listed users."""
+    def rank_topk(self, user_ids, K, out_ids=None, out_scores=None, dense_batch_pairs=1 << 28):
+        """Top-K (ids int32 [n,K], scores fp32 [n,K]) for the listed users: the fused kernel up to K = 32, dense rows +
+        partial ranking up to K = 1024 (`dense_batch_pairs` bounds users x items of one dense batch)."""
         torch = _torch()
         u = self._dev_i32(user_ids)
         n = u.numel()
@@ -227,8 +230,33 @@ class HipScorer:
             out_ids = torch.empty((n, K), dtype=torch.int32, device=self.device)
         if out_scores is None:
             out_scores = torch.empty((n, K), dtype=torch.float32, device=self.device)
-        self._check(self._lib.ifr_rank_topk(self._h, u.data_ptr(), n, int(K), out_ids.data_ptr(),
-                                            out_scores.data_ptr(), self._stream()))
+        if K <= MAX_FUSED_TOPK:
+            self._check(self._lib.ifr_rank_topk(self._h, u.data_ptr(), n, int(K), out_ids.data_ptr(),
+                                                out_scores.data_ptr(), self._stream()))
+            return out_ids, out_scores
+        # cut-offs beyond the fused kernel: dense rows in batches + partial ranking (ifr_select_topk)
+        step = max(1, int(dense_batch_pairs // max(1, self.catalogue_items)))
+        buf = None
+        for b in range(0, n, step):
+            ub = u[b:b + step]
+            dense = self.score_dense(ub, None if buf is None else buf[: ub.numel()])
+            buf = dense if buf is None else buf
+            self.select_topk(ub, dense, K, out_ids[b:b + step], out_scores[b:b + step])
+        return out_ids, out_scores
+
+    def select_topk(self, user_ids, scores, K, out_ids=None, out_scores=None):
+        """The K <= 1024 best candidates of dense score rows in the order of rank_full (partial ranking)."""
+        torch = _torch()
+        u = self._dev_i32(user_ids)
+        n = u.numel()
+        if out_ids is None:
+            out_ids = torch.empty((n, K), dtype=torch.int32, device=self.device)
+        if out_scores is None:
+            out_scores = torch.empty((n, K), dtype=torch.float32, device=self.device)
+        if not (out_ids.is_contiguous() and out_scores.is_contiguous()):
+            raise ValueError("select_topk: output tensors must be contiguous")
+        self._check(self._lib.ifr_select_topk(self._h, u.data_ptr(), n, scores.data_ptr(), scores.stride(0), int(K),
+                                              out_ids.data_ptr(), out_scores.data_ptr(), self._stream()))
         return out_ids, out_scores
 
     def eval_topk_metrics(self, user_ids, topk_ids, ks):

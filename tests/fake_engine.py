@@ -55,8 +55,9 @@ class OracleEngine:
         ids = np.full((len(users), K), -1, np.int32)
         sc = np.full((len(users), K), -np.inf, np.float32)
         for r, u in enumerate(users):
-            s = self._scores(int(u))
-            cand = np.setdiff1d(np.arange(self.n_items), self._row(self.ex, int(u)))
+            # K <= 32: the fused kernel ranks the items the model knows; beyond: dense rows over the catalogue
+            s = self._scores(int(u)) if K <= 32 else self._padded(int(u))
+            cand = np.setdiff1d(np.arange(len(s)), self._row(self.ex, int(u)))
             head = orc.canonical_rank(cand, s[cand], K)
             ids[r, : len(head)] = head
             sc[r, : len(head)] = s[head]

@@ -257,3 +257,19 @@ def test_exact_ann_backend_matches_base_model(toy):
     assert not (set(rec2) & seen) and set(rec2) <= set(rec[0])
     with pytest.raises(ValueError):
         ann.recommend_batch(["nobody"], k=3)
+
+
+def test_cutoffs_beyond_32_use_partial_ranking_and_match_the_list_path(toy):
+    """NDCG@50 / Recall@100 / Precision@50 through the dense + ifr_select_topk path equal the values of the
+    full-ranking path (forced by adding MRR to the metric list)."""
+    d = toy
+    train_set, test_set, val_set = _sets(d)
+    model = _model(d, "bpr", train_set)
+    mets = [M.NDCG(k=50), M.Recall(k=100), M.Precision(k=50), M.NDCG(k=10)]
+    a_avg, a_usr = ranking_eval(model, mets, train_set, test_set, val_set, rating_threshold=float(d["rating_threshold"]))
+    model2 = _model(d, "bpr", train_set)
+    b_avg, b_usr = ranking_eval(model2, mets + [M.MRR()], train_set, test_set, val_set, rating_threshold=float(d["rating_threshold"]))
+    np.testing.assert_allclose(a_avg, b_avg[:4], rtol=0, atol=1e-12)
+    for i in range(4):
+        assert a_usr[i].keys() == b_usr[i].keys()
+        np.testing.assert_allclose([a_usr[i][u] for u in a_usr[i]], [b_usr[i][u] for u in a_usr[i]], rtol=0, atol=1e-12)

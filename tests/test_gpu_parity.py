@@ -282,3 +282,53 @@ def test_golden_reference_fixture(torch, toy, model):
     j = names.index("auc@-1")
     assert np.abs(auc - ref[:, j]).max() < 1e-4          # a near-tie may flip single pairs
     assert abs(auc.mean() - ref[:, j].mean()) < 1e-6
+
+
+@pytest.mark.parametrize("K", [33, 100, 1000])
+def test_partial_ranking_beyond_the_fused_cutoff(torch, K):
+    """ifr_select_topk (Recommender.rank(k != -1), recommender.py:644-649) = the head of the full ranking: against
+    ifr_rank_full on the same dense rows (ids and scores bit for bit), against the oracle's lists, and through
+    rank_topk, which switches to it for K > 32.  Dense scores equal the fused kernel's, so K <= 32 heads agree too."""
+    w = _workload(77 + K, 300, 3001, 64, True)
+    sc = _scorer(w)
+    users = np.r_[np.arange(w["n_users"]), [3, 3]].astype(np.int32)
+    dense = sc.score_dense(users)
+    ids, scores = sc.select_topk(users, dense, K)
+    full, n_cand = sc.rank_full(users, dense)
+    assert (n_cand >= K).all()
+    assert torch.equal(ids, full[:, :K])
+    assert torch.equal(scores, torch.gather(dense, 1, ids.long()))
+    o_ids, _, _, _ = _oracle(w, users, [K], K, sc.chain_order())
+    np.testing.assert_array_equal(ids.cpu().numpy(), o_ids)
+    ids2, scores2 = sc.rank_topk(users, K, dense_batch_pairs=100 * 3001)          # several dense batches
+    assert torch.equal(ids2, ids) and torch.equal(scores2, scores)
+    fused, _ = sc.rank_topk(users, 32)
+    assert torch.equal(fused, ids[:, :32])
+
+
+def test_partial_ranking_ties_short_rows_and_nan(torch):
+    torch_ = torch
+    from recommenders_amd import HipScorer
+    n_items, k = 700, 8
+    U = np.zeros((6, k), np.float32); V = np.zeros((n_items, k), np.float32)
+    U[:, 0] = 1.0
+    V[:, 0] = np.repeat(np.arange(7, 0, -1), 100)                  # seven plateaus of 100 equal scores
+    excl = [np.zeros(0, int), np.arange(0, 650), np.arange(n_items), np.arange(95, 105), np.arange(1, n_items, 2), np.zeros(0, int)]
+    ptr = np.cumsum([0] + [len(e) for e in excl]).astype(np.int64)
+    sc = HipScorer(0)
+    sc.set_factors(U, V, None, None)
+    sc.set_exclusion_csr(ptr, np.concatenate(excl).astype(np.int32))
+    users = np.arange(6, dtype=np.int32)
+    dense = sc.score_dense(users)
+    dense[5, 300] = float("nan")                                     # NaN ranks first, like argsort()[::-1]
+    for K in (40, 150, 1024):
+        ids, scores = sc.select_topk(users, dense, K)
+        full, n_cand = sc.rank_full(users, dense)
+        want = full[:, :K] if full.shape[1] >= K else torch_.nn.functional.pad(full, (0, K - full.shape[1]), value=-1)
+        assert torch_.equal(ids, want)
+        ok = ids >= 0
+        got = scores[ok]
+        ref = torch_.gather(dense, 1, ids.clamp(min=0).long())[ok]
+        assert torch_.equal(torch_.nan_to_num(got, nan=123.0), torch_.nan_to_num(ref, nan=123.0))
+        assert torch_.isneginf(scores[~ok]).all()
+    assert (ids[2] == -1).all() and ids[5, 0] == 300 and (ids[1, :50].cpu().numpy() == np.arange(650, 700)).all()

@@ -27,3 +27,8 @@ bu = users[:step]
 ev[0].record(); dense = sc.score_dense(bu); ev[1].record(); ranked, n_cand = sc.rank_full(bu, dense); ev[2].record()
 pl, _, _ = sc.eval_ranked_metrics(bu, ranked, n_cand, [10, -1]); ev[3].record(); torch.cuda.synchronize()
 print("one batch of", step, "users: dense %.2f ms, rank_full %.2f ms, metrics %.2f ms" % (ev[0].elapsed_time(ev[1]), ev[1].elapsed_time(ev[2]), ev[2].elapsed_time(ev[3])))
+for K in (100, 1000):
+    sc.rank_topk(users, K); torch.cuda.synchronize()
+    t = time.perf_counter(); ids, _ = sc.rank_topk(users, K); nr = (ids >= 0).sum(dim=1).to(torch.int32)
+    pl, _, _ = sc.eval_ranked_metrics(users, ids, nr, [K]); torch.cuda.synchronize(); dt = time.perf_counter() - t
+    print(f"dense + select_topk(K={K}) + list metrics: {dt*1e3:.1f} ms for {nu} users = {nu/dt/1e3:.1f} K users/s", flush=True)
