@@ -256,3 +256,18 @@ def test_facade_matches_reference(torch, toy, name, form):
     ranked = model.ranked_items[u]
     np.testing.assert_array_equal(ranked[:19], d[f"{name}__ranked_head"][r][:19])
     assert len(ranked) == d[f"{name}__n_cand"][r]
+
+
+@pytest.mark.parametrize("form", ["dense", "csr"])
+def test_item_item_cutoff_beyond_32_through_partial_ranking(torch, form):
+    """rank_topk(K = 50) of an item-item model: dense rows (ifr_score_dense) + ifr_select_topk, against the oracle."""
+    if form == "dense":
+        w = _workload(91, 150, 3001, 25, pen=True)
+    else:
+        w = _workload(92, 150, 6000, 30, row_nnz=80, weights="prob", pen=True)
+    sc = _scorer(w)
+    users = np.arange(w["n_users"], dtype=np.int32)
+    ids, scores = sc.rank_topk(users, 50)
+    o_ids, o_sc, _, _ = _oracle(w, sc, users, [50], 50)
+    np.testing.assert_array_equal(ids.cpu().numpy(), o_ids)
+    np.testing.assert_array_equal(scores.cpu().numpy(), o_sc)

@@ -32,3 +32,11 @@ for K in (100, 1000):
     t = time.perf_counter(); ids, _ = sc.rank_topk(users, K); nr = (ids >= 0).sum(dim=1).to(torch.int32)
     pl, _, _ = sc.eval_ranked_metrics(users, ids, nr, [K]); torch.cuda.synchronize(); dt = time.perf_counter() - t
     print(f"dense + select_topk(K={K}) + list metrics: {dt*1e3:.1f} ms for {nu} users = {nu/dt/1e3:.1f} K users/s", flush=True)
+bu = users[:step]
+dense = sc.score_dense(bu)
+for K in (100, 1000):
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    sc.select_topk(bu, dense, K); torch.cuda.synchronize()
+    ev[0].record(); ids, _ = sc.select_topk(bu, dense, K); ev[1].record()
+    nr = (ids >= 0).sum(dim=1).to(torch.int32); pl, _, _ = sc.eval_ranked_metrics(bu, ids, nr, [K]); ev[2].record(); torch.cuda.synchronize()
+    print(f"K={K}: select_topk {ev[0].elapsed_time(ev[1]):.2f} ms, count + list metrics {ev[1].elapsed_time(ev[2]):.2f} ms per {step} users", flush=True)
