@@ -165,6 +165,14 @@ int ifr_eval_ranked_metrics(ifr_handle h, const int32_t *user_ids, int64_t n, co
                             int64_t ld, const int32_t *n_ranked, const int32_t *ks, int n_k,
                             double *out_per_user, int32_t *evaluated, double *out_sums, void *stream);
 
+/* The same columns as ifr_eval_ranked_metrics, computed straight from dense score rows (as written by
+ * ifr_score_dense) without building the ranking: every list metric (cornac/metrics/ranking.py:67-123,
+ * 194-223, 240-274, 500-527) depends only on the positions of the user's positives in the ranking
+ * "score descending, item index ascending, exclusions left out", and position(p) = number of candidates
+ * that beat p.  Rows with up to 4096 positives.  scores: dev [n][ld], ld >= catalogue items. */
+int ifr_eval_dense_metrics(ifr_handle h, const int32_t *user_ids, int64_t n, const float *scores, int64_t ld, const int32_t *ks,
+                           int n_k, double *out_per_user, int32_t *evaluated, double *out_sums, void *stream);
+
 /* Full score rows for a batch of users (bit-identical to the scores the fused kernel ranks).
  * Replaces Recommender.score(user_idx) (cornac/models/recommender.py:480-498) /
  * item_scores of rank (:643).  out: dev [n][ld] fp32, ld >= n_items. */

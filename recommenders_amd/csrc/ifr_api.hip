@@ -823,6 +823,33 @@ int ifr_eval_ranked_metrics(ifr_handle h, const int32_t *user_ids, int64_t n, co
     return sum_columns(h, out_per_user, evaluated, n, IFR_METRICS_PER_K * n_k + 2, out_sums, s);
 }
 
+int ifr_eval_dense_metrics(ifr_handle h, const int32_t *user_ids, int64_t n, const float *scores, int64_t ld, const int32_t *ks,
+                           int n_k, double *out_per_user, int32_t *evaluated, double *out_sums, void *stream)
+{
+    if (!h) return IFR_ERR_ARG;
+    if (!h->tr_ptr) return fail(h, IFR_ERR_STATE, "ifr_eval_dense_metrics: truth CSR not set");
+    const int64_t cat = catalogue_items(h);
+    if (!user_ids || !scores || !ks || !out_per_user || !evaluated || !out_sums || n <= 0 || ld < cat)
+        return fail(h, IFR_ERR_ARG, "ifr_eval_dense_metrics: null/empty argument or ld < catalogue items");
+    if (n_k < 1 || n_k > ifr::MAX_KS) return fail(h, IFR_ERR_ARG, "ifr_eval_dense_metrics: n_k in [1,8]");
+    for (int q = 0; q < n_k; ++q)
+        if (ks[q] == 0 || ks[q] < -1) return fail(h, IFR_ERR_ARG, "ifr_eval_dense_metrics: cut-off must be -1 or > 0");
+    if (h->tr_max_row > ifr::DM_MAX_POS)
+        return fail(h, IFR_ERR_ARG, "ifr_eval_dense_metrics: more than 4096 positives in one row (use ifr_rank_full + ifr_eval_ranked_metrics)");
+    if (n > (int64_t)0xffffffffu / ifr::BLOCK) return fail(h, IFR_ERR_ARG, "ifr_eval_dense_metrics: batch too large");
+    IFR_HIP(h, hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)stream;
+    ifr::DenseMetricParams p;
+    p.scores = scores; p.ld = ld; p.user_ids = user_ids; p.n_items = (int)cat; p.n_k = n_k;
+    for (int q = 0; q < ifr::MAX_KS; ++q) p.ks[q] = q < n_k ? ks[q] : 1;
+    p.ex_ptr = h->ex_ptr; p.ex_idx = h->ex_idx; p.ex_rows = h->ex_rows;
+    p.tr_ptr = h->tr_ptr; p.tr_idx = h->tr_idx; p.tr_rows = h->tr_rows;
+    p.per_user = out_per_user; p.evaluated = evaluated;
+    hipLaunchKernelGGL(ifr::metrics_dense_kernel, dim3((unsigned)n), dim3(ifr::BLOCK), 0, s, p);
+    IFR_HIP(h, hipGetLastError());
+    return sum_columns(h, out_per_user, evaluated, n, IFR_METRICS_PER_K * n_k + 2, out_sums, s);
+}
+
 int ifr_rank_items(ifr_handle h, const float *scores, int64_t n_scores, const int32_t *items, int64_t m,
                    int32_t *out_ids, void *stream)
 {

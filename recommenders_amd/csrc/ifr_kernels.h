@@ -728,6 +728,213 @@ __global__ __launch_bounds__(BLOCK) void metrics_list_kernel(ListMetricParams p)
     }
 }
 
+// ------------------------------------------------------------------------------------
+// List metrics straight from dense score rows, without building the ranking.  Every metric of the
+// list kernel above depends only on WHERE the user's positives stand in the full ranking (score
+// descending, item index ascending, excluded items left out): position(p) = number of candidates that
+// beat p.  One workgroup per row: the positives' keys are sorted in LDS; every item finds, by a
+// branch-free search, how many positives beat IT (j) and bumps cnt[j] -- it beats the positives from
+// j on --; excluded items take their bump back; a prefix sum over cnt gives every positive's position.
+// O(I log P) instead of the O(I log I) sort + O(I log P) sweep; one read of the row.
+// ------------------------------------------------------------------------------------
+constexpr int DM_MAX_POS = 4096;
+
+struct DenseMetricParams {
+    const float *scores;         // [n][ld]
+    int64_t ld;
+    const int32_t *user_ids;
+    int n_items;                 // columns ranked (catalogue)
+    const int64_t *ex_ptr;
+    const int32_t *ex_idx;
+    int64_t ex_rows;
+    const int64_t *tr_ptr;
+    const int32_t *tr_idx;
+    int64_t tr_rows;
+    int ks[MAX_KS];
+    int n_k;
+    double *per_user;            // [n][NM*n_k + 2]
+    int32_t *evaluated;
+};
+
+__device__ __forceinline__ unsigned long long rank_key(float s, int item)
+{
+    uint32_t b = __float_as_uint(s);
+    b = (b & 0x80000000u) ? ~b : (b | 0x80000000u);          // ascending-orderable
+    return ((unsigned long long)(~b) << 32) | (uint32_t)item;   // smaller key = earlier in the ranking
+}
+
+__global__ __launch_bounds__(BLOCK) void metrics_dense_kernel(DenseMetricParams p)
+{
+    __shared__ unsigned long long kp[DM_MAX_POS];
+    __shared__ uint32_t cnt[DM_MAX_POS + 1];
+    __shared__ double red[BLOCK / 64][2 * MAX_KS + 1];
+    __shared__ int red_i[BLOCK / 64][MAX_KS + 2];
+    __shared__ uint32_t wsum[BLOCK / 64];
+    __shared__ int s_valid, s_nex;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t i = blockIdx.x;
+    const int ncol = NM * p.n_k + 2;
+    const int u = p.user_ids[i];
+    const float *row = p.scores + i * p.ld;
+    int64_t b = 0, e = 0, eb = 0, ee = 0;
+    if (u >= 0 && u < p.tr_rows) { b = p.tr_ptr[u]; e = p.tr_ptr[u + 1]; }
+    if (p.ex_ptr != nullptr && u >= 0 && u < p.ex_rows) { eb = p.ex_ptr[u]; ee = p.ex_ptr[u + 1]; }
+    const int n_pos = (int)(e - b);
+    double *out = p.per_user + i * ncol;
+    if (n_pos == 0) {
+        if (tid == 0) p.evaluated[i] = 0;
+        for (int c = tid; c < ncol; c += BLOCK) out[c] = IFR_NAN;
+        return;
+    }
+    if (tid == 0) { s_valid = 0; s_nex = 0; }
+    __syncthreads();
+    // ---- keys of the positives that are candidates, sorted ascending (best first), padded with the worst key
+    int np2 = 1;
+    while (np2 < n_pos) np2 <<= 1;
+    {
+        int v = 0;
+        for (int q = tid; q < np2; q += BLOCK) {
+            unsigned long long k = ~0ull;
+            if (q < n_pos) {
+                const int it = p.tr_idx[b + q];
+                if (it >= 0 && it < p.n_items && !in_sorted_row(p.ex_idx, eb, ee, it)) { k = rank_key(row[it], it); ++v; }
+            }
+            kp[q] = k;
+        }
+        if (v) atomicAdd(&s_valid, v);
+    }
+    __syncthreads();
+    for (int kk = 2; kk <= np2; kk <<= 1) {
+        for (int j = kk >> 1; j > 0; j >>= 1) {
+            for (int q = tid; q < np2; q += BLOCK) {
+                const int x = q ^ j;
+                if (x > q) {
+                    const unsigned long long a = kp[q], c = kp[x];
+                    const bool up = (q & kk) == 0;
+                    if ((a > c) == up) { kp[q] = c; kp[x] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    const int P = s_valid;                                   // positives that stand in the ranking
+    for (int q = tid; q <= P; q += BLOCK) cnt[q] = 0u;
+    __syncthreads();
+    // positives that beat `key`: branch-free lower bound over the padded array (pads beat nothing)
+    auto beaten_from = [&](unsigned long long key) -> int {
+        int c = 0;
+        for (int step = np2 >> 1; step >= 1; step >>= 1) c += kp[c + step - 1] < key ? step : 0;
+        c += kp[c] < key ? 1 : 0;
+        return min(c, P);
+    };
+    // ---- every item bumps the first positive it beats; four independent searches per thread
+    int it0 = 0;
+    if ((p.ld & 3) == 0 && (reinterpret_cast<uintptr_t>(p.scores) & 15) == 0) {
+        const int n4 = p.n_items & ~3;
+        for (int it = 4 * tid; it < n4; it += 4 * BLOCK) {
+            const float4 s = *reinterpret_cast<const float4 *>(row + it);
+            const unsigned long long k0 = rank_key(s.x, it), k1 = rank_key(s.y, it + 1), k2 = rank_key(s.z, it + 2),
+                                     k3 = rank_key(s.w, it + 3);
+            int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+            for (int step = np2 >> 1; step >= 1; step >>= 1) {
+                const unsigned long long a0 = kp[c0 + step - 1], a1 = kp[c1 + step - 1], a2 = kp[c2 + step - 1], a3 = kp[c3 + step - 1];
+                c0 += a0 < k0 ? step : 0;
+                c1 += a1 < k1 ? step : 0;
+                c2 += a2 < k2 ? step : 0;
+                c3 += a3 < k3 ? step : 0;
+            }
+            const unsigned long long a0 = kp[c0], a1 = kp[c1], a2 = kp[c2], a3 = kp[c3];
+            c0 += a0 < k0 ? 1 : 0;
+            c1 += a1 < k1 ? 1 : 0;
+            c2 += a2 < k2 ? 1 : 0;
+            c3 += a3 < k3 ? 1 : 0;
+            atomicAdd(&cnt[min(c0, P)], 1u);
+            atomicAdd(&cnt[min(c1, P)], 1u);
+            atomicAdd(&cnt[min(c2, P)], 1u);
+            atomicAdd(&cnt[min(c3, P)], 1u);
+        }
+        it0 = n4;
+    }
+    for (int it = it0 + tid; it < p.n_items; it += BLOCK) atomicAdd(&cnt[beaten_from(rank_key(row[it], it))], 1u);
+    {
+        int c = 0;
+        for (int64_t q = eb + tid; q < ee; q += BLOCK) {
+            const int it = p.ex_idx[q];
+            if (it >= 0 && it < p.n_items) { atomicSub(&cnt[beaten_from(rank_key(row[it], it))], 1u); ++c; }
+        }
+        if (c) atomicAdd(&s_nex, c);
+    }
+    __syncthreads();
+    const int len = p.n_items - s_nex;                       // candidates = length of the ranking
+    // ---- inclusive prefix over cnt[0..P]: cnt[q] = candidates that beat positive q, plus itself
+    const int seg = (P + BLOCK) / BLOCK;                     // entries per thread, ceil((P + 1) / BLOCK)
+    {
+        uint32_t mine = 0;
+        for (int v = 0; v < seg; ++v) { const int q = tid * seg + v; if (q <= P) mine += cnt[q]; }
+        uint32_t incl = mine;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { const uint32_t t = __shfl_up(incl, off); if (lane >= off) incl += t; }
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        uint32_t run = incl - mine;
+        for (int w = 0; w < wave; ++w) run += wsum[w];
+        for (int v = 0; v < seg; ++v) { const int q = tid * seg + v; if (q <= P) { run += cnt[q]; cnt[q] = run; } }
+    }
+    __syncthreads();
+    // ---- the metrics from the positions, hits in ranking order (q ascending)
+    double dcg[MAX_KS], crr[MAX_KS], ap = 0.0;
+    int tp[MAX_KS], first = 0x7fffffff;
+#pragma unroll
+    for (int q = 0; q < MAX_KS; ++q) { dcg[q] = 0.0; crr[q] = 0.0; tp[q] = 0; }
+    for (int q = tid; q < P; q += BLOCK) {
+        const int pos = (int)cnt[q] - 1;
+        const double disc = 1.0 / log2((double)pos + 2.0);
+        const double rr = 1.0 / (double)(pos + 1);
+        ap += (double)(q + 1) * rr;
+        first = min(first, pos);
+#pragma unroll
+        for (int c = 0; c < MAX_KS; ++c) {
+            if (c < p.n_k && (p.ks[c] <= 0 || pos < p.ks[c])) { dcg[c] += disc; crr[c] += rr; ++tp[c]; }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < MAX_KS; ++q) {
+        double a = dcg[q], c = crr[q];
+        int t = tp[q];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) { a += __shfl_xor(a, off); c += __shfl_xor(c, off); t += __shfl_xor(t, off); }
+        if (lane == 0) { red[wave][2 * q] = a; red[wave][2 * q + 1] = c; red_i[wave][q] = t; }
+    }
+    {
+        double a = ap;
+        int f = first;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) { a += __shfl_xor(a, off); f = min(f, __shfl_xor(f, off)); }
+        if (lane == 0) { red[wave][2 * MAX_KS] = a; red_i[wave][MAX_KS] = f; }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        p.evaluated[i] = 1;
+        double apt = 0.0;
+        int ft = 0x7fffffff;
+        for (int w = 0; w < BLOCK / 64; ++w) { apt += red[w][2 * MAX_KS]; ft = min(ft, red_i[w][MAX_KS]); }
+        for (int q = 0; q < p.n_k; ++q) {
+            double a = 0.0, c = 0.0;
+            int t = 0;
+            for (int w = 0; w < BLOCK / 64; ++w) { a += red[w][2 * q]; c += red[w][2 * q + 1]; t += red_i[w][q]; }
+            const int k = p.ks[q];
+            const int ideal = k > 0 ? min(k, n_pos) : n_pos;
+            const int trunc = k > 0 ? min(k, len) : len;
+            double idcg = 0.0, icrr = 0.0;
+            for (int r = 0; r < ideal; ++r) idcg += 1.0 / log2((double)r + 2.0);
+            for (int r = 0; r < min(n_pos, trunc); ++r) icrr += 1.0 / (double)(r + 1);
+            store_at_k(out + NM * q, a, idcg, c, icrr, t, n_pos, k > 0 ? (double)k : (double)len);
+        }
+        out[NM * p.n_k] = ft == 0x7fffffff ? IFR_NAN : 1.0 / (double)(ft + 1);
+        out[NM * p.n_k + 1] = apt / (double)n_pos;
+    }
+}
+
 // Columns [n_known, n_cat) of every score row := the row's minimum over [0, n_known): items unknown to
 // the model get the user's minimum score (cornac/models/recommender.py:631-635).  NaN-free rows assumed
 // (fminf skips NaN like np.min does not; the reference's scores here are finite).

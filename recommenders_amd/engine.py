@@ -14,6 +14,7 @@ METRICS_PER_K = 6      # ndcg, recall, precision, hit ratio, f1, ncrr (include/i
 METRIC_COLUMNS = ("ndcg", "recall", "precision", "hit", "f1", "ncrr")
 MAX_FUSED_TOPK = 32    # ifr_rank_topk (include/ifr.h IFR_MAX_TOPK)
 MAX_SELECT_TOPK = 1024 # ifr_select_topk
+MAX_DENSE_METRIC_POS = 4096   # ifr_eval_dense_metrics: positives per row
 
 
 class IfrError(RuntimeError):
@@ -288,6 +289,22 @@ class HipScorer:
         sums = torch.empty((ncol + 1,), dtype=torch.float64, device=self.device)
         self._check(self._lib.ifr_eval_ranked_metrics(
             self._h, u.data_ptr(), n, ranked.data_ptr(), ranked.stride(0), n_ranked.data_ptr(), ks_arr, len(ks),
+            per_user.data_ptr(), evaluated.data_ptr(), sums.data_ptr(), self._stream()))
+        return per_user, evaluated, sums
+
+    def eval_dense_metrics(self, user_ids, scores, ks):
+        """The columns of eval_ranked_metrics straight from dense score rows (positions of the positives by
+        counting, no ranking is built); rows with at most MAX_DENSE_METRIC_POS positives."""
+        torch = _torch()
+        u = self._dev_i32(user_ids)
+        n = u.numel()
+        ks_arr = (ctypes.c_int32 * len(ks))(*[int(k) for k in ks])
+        ncol = METRICS_PER_K * len(ks) + 2
+        per_user = torch.empty((n, ncol), dtype=torch.float64, device=self.device)
+        evaluated = torch.empty((n,), dtype=torch.int32, device=self.device)
+        sums = torch.empty((ncol + 1,), dtype=torch.float64, device=self.device)
+        self._check(self._lib.ifr_eval_dense_metrics(
+            self._h, u.data_ptr(), n, scores.data_ptr(), scores.stride(0), ks_arr, len(ks),
             per_user.data_ptr(), evaluated.data_ptr(), sums.data_ptr(), self._stream()))
         return per_user, evaluated, sums
 

@@ -13,7 +13,7 @@ import numpy as np
 import scipy.sparse as sp
 
 from . import dist as ifr_dist
-from .engine import METRIC_COLUMNS, METRICS_PER_K
+from .engine import MAX_DENSE_METRIC_POS, METRIC_COLUMNS, METRICS_PER_K
 from .metrics import metric_kind
 
 MAX_FUSED_K = 32          # fused score + top-K kernel (ifr_rank_topk)
@@ -281,6 +281,8 @@ def ranking_eval(model, metrics, train_set, test_set, val_set=None, rating_thres
         if need_list or need_auc:
             step = max(1, int(batch_pairs // max(1, n_items)))
             lst_ks = ks if ks else [-1]
+            max_pos = int(np.diff(truth.indptr).max()) if truth.shape[0] else 0
+            dense_metrics = max_pos <= MAX_DENSE_METRIC_POS
             per_list = np.empty((n, METRICS_PER_K * len(lst_ks) + 2)) if need_list else None
             auc = np.empty(n) if need_auc else None
             for b in range(0, n, step):
@@ -288,7 +290,11 @@ def ranking_eval(model, metrics, train_set, test_set, val_set=None, rating_thres
                 dense = eng.score_dense(bu)
                 if need_auc:
                     auc[b:b + step] = eng.auc_dense(bu, dense).cpu().numpy()
-                if need_list:
+                if need_list and dense_metrics:
+                    # positions of the positives by counting: no ranking is built
+                    pl, _, _ = eng.eval_dense_metrics(bu, dense, lst_ks)
+                    per_list[b:b + step] = pl.cpu().numpy()
+                elif need_list:
                     ranked, n_cand = eng.rank_full(bu, dense)
                     pl, _, _ = eng.eval_ranked_metrics(bu, ranked, n_cand, lst_ks)
                     per_list[b:b + step] = pl.cpu().numpy()

@@ -93,6 +93,10 @@ class OracleEngine:
         sums = np.concatenate([out[ev == 1].sum(0), [ev.sum()]])
         return torch.from_numpy(out), torch.from_numpy(ev), torch.from_numpy(sums)
 
+    def eval_dense_metrics(self, user_ids, dense, ks):
+        ranked, n_cand = self.rank_full(user_ids, dense)
+        return self.eval_ranked_metrics(user_ids, ranked, n_cand, ks)
+
     def eval_ranked_metrics(self, user_ids, ranked, n_ranked, ks):
         users, rk, nr = np.asarray(user_ids), ranked.numpy(), n_ranked.numpy()
         out = np.full((len(users), METRICS_PER_K * len(ks) + 2), np.nan)

@@ -332,3 +332,37 @@ def test_partial_ranking_ties_short_rows_and_nan(torch):
         assert torch_.equal(torch_.nan_to_num(got, nan=123.0), torch_.nan_to_num(ref, nan=123.0))
         assert torch_.isneginf(scores[~ok]).all()
     assert (ids[2] == -1).all() and ids[5, 0] == 300 and (ids[1, :50].cpu().numpy() == np.arange(650, 700)).all()
+
+
+def test_dense_row_metrics_equal_the_ranked_list_metrics(torch):
+    """ifr_eval_dense_metrics (positions of the positives by counting) against ifr_rank_full +
+    ifr_eval_ranked_metrics on the same rows: every column, also with plateaus of tied scores, positives that are
+    excluded or beyond the catalogue, rows without positives, and the unaligned-row code path."""
+    w = _workload(12, 120, 901, 32, True, mean=40)
+    # a few positives that are also excluded: they are not in the ranking, so they are never hits
+    tp, ti = w["truth_ptr"], w["truth_idx"]
+    ex_rows = [np.union1d(w["excl_idx"][w["excl_ptr"][u]: w["excl_ptr"][u + 1]], ti[tp[u]: tp[u + 1]][:2] if u % 5 == 0 else [])
+               for u in range(w["n_users"])]
+    w = dict(w, excl_ptr=np.cumsum([0] + [len(r) for r in ex_rows]).astype(np.int64),
+             excl_idx=np.concatenate(ex_rows).astype(np.int32))
+    sc = _scorer(w)
+    users = np.arange(w["n_users"], dtype=np.int32)
+    ks = [-1, 5, 10, 100, 2000]
+    for variant in ("scores", "plateaus", "unaligned"):
+        dense = sc.score_dense(users)
+        if variant == "plateaus":
+            dense = torch.round(dense * 4) / 4                      # many exact ties: order falls back on the item index
+        if variant == "unaligned":
+            wide = torch.empty((dense.shape[0], dense.shape[1] + 2), dtype=dense.dtype, device=dense.device)
+            wide[:, : dense.shape[1]] = dense
+            dense = wide[:, : dense.shape[1]]                       # row stride 903: rows are not 16-byte aligned
+            dense = dense[1:]
+            us = users[1:]
+        else:
+            us = users
+        ranked, n_cand = sc.rank_full(us, dense.contiguous() if variant != "unaligned" else dense.clone())
+        a, a_ev, a_sum = sc.eval_ranked_metrics(us, ranked, n_cand, ks)
+        b, b_ev, b_sum = sc.eval_dense_metrics(us, dense, ks)
+        assert torch.equal(a_ev, b_ev) and a_ev.any() and not a_ev.all()
+        np.testing.assert_allclose(b.cpu().numpy(), a.cpu().numpy(), rtol=0, atol=1e-13, equal_nan=True)
+        np.testing.assert_allclose(b_sum.cpu().numpy(), a_sum.cpu().numpy(), rtol=1e-13)

@@ -40,3 +40,16 @@ for K in (100, 1000):
     ev[0].record(); ids, _ = sc.select_topk(bu, dense, K); ev[1].record()
     nr = (ids >= 0).sum(dim=1).to(torch.int32); pl, _, _ = sc.eval_ranked_metrics(bu, ids, nr, [K]); ev[2].record(); torch.cuda.synchronize()
     print(f"K={K}: select_topk {ev[0].elapsed_time(ev[1]):.2f} ms, count + list metrics {ev[1].elapsed_time(ev[2]):.2f} ms per {step} users", flush=True)
+def run2():
+    for b in range(0, nu, step):
+        bu = users[b:b + step]
+        dense = sc.score_dense(bu)
+        pl, _, _ = sc.eval_dense_metrics(bu, dense, [10, -1])
+    torch.cuda.synchronize()
+run2()
+t = time.perf_counter(); run2(); dt = time.perf_counter() - t
+print(f"dense + eval_dense_metrics (k = 10, -1, MRR, MAP): {dt*1e3:.1f} ms for {nu} users = {nu/dt/1e3:.1f} K users/s", flush=True)
+ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+bu = users[:step]; dense = sc.score_dense(bu)
+ev[0].record(); sc.eval_dense_metrics(bu, dense, [10, -1]); ev[1].record(); torch.cuda.synchronize()
+print(f"eval_dense_metrics alone: {ev[0].elapsed_time(ev[1]):.2f} ms per {step} users")
