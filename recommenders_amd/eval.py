@@ -16,8 +16,8 @@ from . import dist as ifr_dist
 from .engine import MAX_DENSE_METRIC_POS, METRIC_COLUMNS, METRICS_PER_K
 from .metrics import metric_kind
 
-MAX_FUSED_K = 32          # fused score + top-K kernel (ifr_rank_topk)
-MAX_SELECT_K = 1024       # dense rows + partial ranking (ifr_select_topk)
+MAX_FUSED_K = 32          # fused score + top-K kernel; larger cut-offs, k = -1, MRR and MAP take dense rows +
+                          # ifr_eval_dense_metrics (positions of the positives by counting)
 
 
 # --------------------------------------------------------------------------- CSR preparation
@@ -171,7 +171,7 @@ def plan_metrics(metrics):
             raise ValueError("list-valued k must be expanded by the caller (BaseMethod.organize_metrics does)")
         specs.append((kind, int(k)))
     per_k = [(kind, k) for kind, k in specs if kind in METRIC_COLUMNS]
-    need_list = any(kind in ("mrr", "map") for kind, _ in specs) or any(k <= 0 or k > MAX_SELECT_K for _, k in per_k)
+    need_list = any(kind in ("mrr", "map") for kind, _ in specs) or any(k <= 0 or k > MAX_FUSED_K for _, k in per_k)
     need_auc = any(kind == "auc" for kind, _ in specs)
     ks = sorted({k for _, k in per_k}, key=lambda v: (v <= 0, v))
     return specs, ks, need_auc, need_list
@@ -265,15 +265,9 @@ def ranking_eval(model, metrics, train_set, test_set, val_set=None, rating_thres
         if not need_list and ks:
             kmax = max(ks)
             ids, _ = eng.rank_topk(dev_users, kmax)
-            if kmax <= MAX_FUSED_K:
-                if n_items > eng.n_items:
-                    ids = _append_unknown_items(ids, my_users, excl, eng.n_items, n_items)
-                per_user, _, _ = eng.eval_topk_metrics(dev_users, ids, ks)
-            else:
-                # cut-offs in (32, 1024]: the K best of dense rows (recommender.py:644-649), which already cover
-                # the whole catalogue including items unknown to the model
-                n_ranked = (ids >= 0).sum(dim=1).to(torch.int32)
-                per_user, _, _ = eng.eval_ranked_metrics(dev_users, ids, n_ranked, ks)
+            if n_items > eng.n_items:
+                ids = _append_unknown_items(ids, my_users, excl, eng.n_items, n_items)
+            per_user, _, _ = eng.eval_topk_metrics(dev_users, ids, ks)
             per_user = per_user.cpu().numpy()
             for qi, k in enumerate(ks):
                 for ci, name in enumerate(METRIC_COLUMNS):

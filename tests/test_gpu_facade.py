@@ -259,17 +259,21 @@ def test_exact_ann_backend_matches_base_model(toy):
         ann.recommend_batch(["nobody"], k=3)
 
 
-def test_cutoffs_beyond_32_use_partial_ranking_and_match_the_list_path(toy):
-    """NDCG@50 / Recall@100 / Precision@50 through the dense + ifr_select_topk path equal the values of the
-    full-ranking path (forced by adding MRR to the metric list)."""
+def test_cutoffs_beyond_32_match_the_sorted_list_path(toy):
+    """NDCG@50 / Recall@100 / Precision@50 / MRR / MAP through dense rows + ifr_eval_dense_metrics equal the values
+    computed from explicitly sorted lists (ifr_rank_full + ifr_eval_ranked_metrics)."""
     d = toy
     train_set, test_set, val_set = _sets(d)
     model = _model(d, "bpr", train_set)
-    mets = [M.NDCG(k=50), M.Recall(k=100), M.Precision(k=50), M.NDCG(k=10)]
-    a_avg, a_usr = ranking_eval(model, mets, train_set, test_set, val_set, rating_threshold=float(d["rating_threshold"]))
-    model2 = _model(d, "bpr", train_set)
-    b_avg, b_usr = ranking_eval(model2, mets + [M.MRR()], train_set, test_set, val_set, rating_threshold=float(d["rating_threshold"]))
-    np.testing.assert_allclose(a_avg, b_avg[:4], rtol=0, atol=1e-12)
-    for i in range(4):
-        assert a_usr[i].keys() == b_usr[i].keys()
-        np.testing.assert_allclose([a_usr[i][u] for u in a_usr[i]], [b_usr[i][u] for u in a_usr[i]], rtol=0, atol=1e-12)
+    mets = [M.NDCG(k=50), M.Recall(k=100), M.Precision(k=50), M.NDCG(k=-1), M.MRR(), M.MAP()]
+    avg, per = ranking_eval(model, mets, train_set, test_set, val_set, rating_threshold=float(d["rating_threshold"]))
+    eng = model._hip_engine()
+    users = np.asarray(sorted(per[0].keys()), np.int32)
+    dense = eng.score_dense(users)
+    ranked, n_cand = eng.rank_full(users, dense)
+    pl, _, _ = eng.eval_ranked_metrics(users, ranked, n_cand, [50, 100, -1])
+    pl = pl.cpu().numpy()
+    want = np.stack([pl[:, 0], pl[:, 6 + 1], pl[:, 2], pl[:, 12], pl[:, -2], pl[:, -1]], axis=1)
+    got = np.asarray([[per[j][int(u)] for j in range(len(mets))] for u in users])
+    np.testing.assert_allclose(got, want, rtol=0, atol=1e-12)
+    np.testing.assert_allclose(avg, want.mean(axis=0), rtol=0, atol=1e-12)

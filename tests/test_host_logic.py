@@ -152,8 +152,7 @@ def test_plan_metrics_and_names():
     specs, ks, need_auc, need_list = ifr_eval.plan_metrics([M.NDCG(k=10), M.Recall(k=10), M.Precision(k=5)])
     assert specs == [("ndcg", 10), ("recall", 10), ("precision", 5)] and ks == [5, 10] and not need_auc and not need_list
     assert ifr_eval.plan_metrics([M.AUC()])[2] is True
-    assert ifr_eval.plan_metrics([M.NDCG()])[3] is True and ifr_eval.plan_metrics([M.Recall(k=2000)])[3] is True
-    assert ifr_eval.plan_metrics([M.Recall(k=100)])[3] is False          # partial ranking of dense rows up to 1024
+    assert ifr_eval.plan_metrics([M.NDCG()])[3] is True and ifr_eval.plan_metrics([M.Recall(k=100)])[3] is True
     assert M.NDCG(k=10).name == "NDCG@10" and M.NDCG().name == "NDCG@-1" and M.FMeasure(k=2).name == "F1@2"
     assert M.AUC().name == "AUC" and M.MRR().name == "MRR" and M.MAP().name == "MAP" and M.NDCG().type == "ranking"
     with pytest.raises(TypeError):
@@ -282,21 +281,3 @@ def test_eval_csrs_are_memoised_per_split_and_notice_edits():
     assert d[0] is not a[0]
     ref2 = ev.build_eval_csrs(tr, te, None, 3.0, 40, 50)
     assert (d[0] != ref2[0]).nnz == 0 and (d[1] != ref2[1]).nnz == 0
-
-
-@pytest.mark.parametrize("which", ["toy", "unknowns"])
-def test_cutoffs_between_33_and_1024_take_the_partial_ranking_path(toy, unknowns, which):
-    """k in (32, 1024] without MRR / MAP / k = -1: top-k of dense rows + list metrics on the heads.  Same values
-    as the full-ranking path (forced by MRR), also with items unknown to the model (exclude_unknowns=False)."""
-    d = toy if which == "toy" else unknowns
-    train_set, test_set, val_set = _datasets(d)
-    mets = [M.NDCG(k=40), M.Recall(k=100), M.Precision(k=40), M.HitRatio(k=33)]
-    kw = dict(rating_threshold=float(d["rating_threshold"]), exclude_unknowns=which == "toy")
-    assert ifr_eval.plan_metrics(mets)[3] is False
-    a_avg, a_usr = ifr_eval.ranking_eval(types.SimpleNamespace(is_fitted=True), mets, train_set, test_set, val_set,
-                                         _engine=_engine(d, "mf", test_set.num_users), **kw)
-    b_avg, b_usr = ifr_eval.ranking_eval(types.SimpleNamespace(is_fitted=True), mets + [M.MRR()], train_set, test_set, val_set,
-                                         _engine=_engine(d, "mf", test_set.num_users), **kw)
-    np.testing.assert_allclose(a_avg, b_avg[:4], rtol=0, atol=1e-12)
-    for i in range(4):
-        assert a_usr[i] == pytest.approx(b_usr[i], abs=1e-12)
