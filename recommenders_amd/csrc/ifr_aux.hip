@@ -351,14 +351,15 @@ __global__ __launch_bounds__(SEL_BLOCK) void select_topk_kernel(const float *sco
             k = desc_key(row[it]);
             if (k <= T && !excluded(it)) { lt = k < T; eq = k == T; }
         }
-        if (lt) cand[atomicAdd(&s_cnt, 1u)] = ((unsigned long long)k << 32) | (uint32_t)it;
+        // (the index guard only matters for malformed exclusion rows with duplicates, whose double subtraction skews the histograms)
+        if (lt) { const uint32_t sl = atomicAdd(&s_cnt, 1u); if (sl < (uint32_t)SEL_MAXK) cand[sl] = ((unsigned long long)k << 32) | (uint32_t)it; }
         const unsigned long long bal = __ballot(eq);
         if (lane == 0) wsum[wave] = (uint32_t)__popcll(bal);
         __syncthreads();
         uint32_t before = taken_eq, all = 0;
         for (int w = 0; w < SEL_BLOCK / 64; ++w) { if (w < wave) before += wsum[w]; all += wsum[w]; }
         before += (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
-        if (eq && before < want) cand[atomicAdd(&s_cnt, 1u)] = ((unsigned long long)k << 32) | (uint32_t)it;
+        if (eq && before < want) { const uint32_t sl = atomicAdd(&s_cnt, 1u); if (sl < (uint32_t)SEL_MAXK) cand[sl] = ((unsigned long long)k << 32) | (uint32_t)it; }
         taken_eq += all;
         __syncthreads();
     }
