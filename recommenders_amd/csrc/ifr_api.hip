@@ -845,7 +845,10 @@ int ifr_eval_dense_metrics(ifr_handle h, const int32_t *user_ids, int64_t n, con
     p.ex_ptr = h->ex_ptr; p.ex_idx = h->ex_idx; p.ex_rows = h->ex_rows;
     p.tr_ptr = h->tr_ptr; p.tr_idx = h->tr_idx; p.tr_rows = h->tr_rows;
     p.per_user = out_per_user; p.evaluated = evaluated;
-    hipLaunchKernelGGL(ifr::metrics_dense_kernel, dim3((unsigned)n), dim3(ifr::BLOCK), 0, s, p);
+    int cap = 32;
+    while (cap < h->tr_max_row) cap <<= 1;
+    p.cap = cap;
+    hipLaunchKernelGGL(ifr::metrics_dense_kernel, dim3((unsigned)n), dim3(ifr::BLOCK), (size_t)cap * 12 + 16, s, p);
     IFR_HIP(h, hipGetLastError());
     return sum_columns(h, out_per_user, evaluated, n, IFR_METRICS_PER_K * n_k + 2, out_sums, s);
 }

@@ -752,6 +752,7 @@ struct DenseMetricParams {
     int64_t tr_rows;
     int ks[MAX_KS];
     int n_k;
+    int cap;                     // LDS entries for the positives: power of two >= the longest truth row
     double *per_user;            // [n][NM*n_k + 2]
     int32_t *evaluated;
 };
@@ -765,8 +766,11 @@ __device__ __forceinline__ unsigned long long rank_key(float s, int item)
 
 __global__ __launch_bounds__(BLOCK) void metrics_dense_kernel(DenseMetricParams p)
 {
-    __shared__ unsigned long long kp[DM_MAX_POS];
-    __shared__ uint32_t cnt[DM_MAX_POS + 1];
+    // sized by the launch for the longest truth row of the handle (p.cap = power of two >= that): short rows
+    // leave room for more resident workgroups
+    extern __shared__ __attribute__((aligned(16))) unsigned char dm_lds[];
+    unsigned long long *const kp = reinterpret_cast<unsigned long long *>(dm_lds);          // [p.cap]
+    uint32_t *const cnt = reinterpret_cast<uint32_t *>(kp + p.cap);                          // [p.cap + 1]
     __shared__ double red[BLOCK / 64][2 * MAX_KS + 1];
     __shared__ int red_i[BLOCK / 64][MAX_KS + 2];
     __shared__ uint32_t wsum[BLOCK / 64];
@@ -848,10 +852,10 @@ __global__ __launch_bounds__(BLOCK) void metrics_dense_kernel(DenseMetricParams 
             c1 += a1 < k1 ? 1 : 0;
             c2 += a2 < k2 ? 1 : 0;
             c3 += a3 < k3 ? 1 : 0;
-            atomicAdd(&cnt[min(c0, P)], 1u);
-            atomicAdd(&cnt[min(c1, P)], 1u);
-            atomicAdd(&cnt[min(c2, P)], 1u);
-            atomicAdd(&cnt[min(c3, P)], 1u);
+            if (c0 < P) atomicAdd(&cnt[c0], 1u);            // cnt[P] (beats no positive) enters no position
+            if (c1 < P) atomicAdd(&cnt[c1], 1u);
+            if (c2 < P) atomicAdd(&cnt[c2], 1u);
+            if (c3 < P) atomicAdd(&cnt[c3], 1u);
         }
         it0 = n4;
     }
