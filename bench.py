@@ -174,10 +174,10 @@ def main():
     auc_out = torch.empty((n,), dtype=torch.float64, device=dev) if args.auc else None
 
     def step():
-        b = step_no[0] & 1
+        buf = step_no[0] & 1
         step_no[0] += 1
-        ids, scores = ids2[b], scores2[b]
-        torch.cuda.current_stream(dev).wait_event(copied[b])      # the copy that last read these buffers is done
+        ids, scores = ids2[buf], scores2[buf]
+        torch.cuda.current_stream(dev).wait_event(copied[buf])      # the copy that last read these buffers is done
         sc.rank_topk(users, TOPK, ids, scores)
         per_user, evaluated, sums = sc.eval_topk_metrics(users, ids, [TOPK])
         if args.auc:
@@ -187,12 +187,12 @@ def main():
                 auc_out[b:b + auc_rows] = sc.auc_dense(ub, dense)
         if world > 1:
             sums = all_reduce(sums)                    # RCCL: per-metric sums + evaluated-user count
-        ready[b].record()
-        copy_stream.wait_event(ready[b])
+        ready[buf].record()
+        copy_stream.wait_event(ready[buf])
         with torch.cuda.stream(copy_stream):
-            h_ids2[b].copy_(ids, non_blocking=True)
-            h_scores2[b].copy_(scores, non_blocking=True)
-            copied[b].record()
+            h_ids2[buf].copy_(ids, non_blocking=True)
+            h_scores2[buf].copy_(scores, non_blocking=True)
+            copied[buf].record()
         return sums
 
     def all_reduce(t, op=None):

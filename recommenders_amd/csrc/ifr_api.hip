@@ -20,7 +20,7 @@ namespace ifr {
 // implemented in ifr_aux.hip
 int launch_auc(const float *scores, int64_t ld, const int32_t *user_ids, int64_t n, int n_items,
                const int64_t *ex_ptr, const int32_t *ex_idx, int64_t ex_rows,
-               const int64_t *tr_ptr, const int32_t *tr_idx, int64_t tr_rows,
+               const int64_t *tr_ptr, const int32_t *tr_idx, int64_t tr_rows, int max_pos,
                double *out, hipStream_t stream);
 int launch_rank_items(const float *scores, int64_t n_scores, const int32_t *items, int64_t m, int32_t *out_ids,
                       void **ws, size_t *ws_bytes, hipStream_t stream);
@@ -911,7 +911,7 @@ int ifr_auc_dense(ifr_handle h, const int32_t *user_ids, int64_t n, const float 
     if (h->tr_max_row > 8192) return fail(h, IFR_ERR_ARG, "ifr_auc_dense: more than 8192 positives in one row");
     IFR_HIP(h, hipSetDevice(h->device));
     int rc = ifr::launch_auc(scores, ld, user_ids, n, (int)cat, h->ex_ptr, h->ex_idx, h->ex_rows, h->tr_ptr,
-                             h->tr_idx, h->tr_rows, out_auc, (hipStream_t)stream);
+                             h->tr_idx, h->tr_rows, h->tr_max_row, out_auc, (hipStream_t)stream);
     if (rc) return fail(h, IFR_ERR_HIP, "ifr_auc_dense: launch failed");
     return IFR_OK;
 }

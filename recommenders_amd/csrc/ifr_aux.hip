@@ -29,7 +29,7 @@ __global__ __launch_bounds__(AUC_BLOCK) void auc_kernel(const float *scores, int
                                                         int64_t ex_rows, const int64_t *tr_ptr, const int32_t *tr_idx,
                                                         int64_t tr_rows, double *out)
 {
-    __shared__ float ps[AUC_MAX_POS];
+    extern __shared__ __attribute__((aligned(16))) float ps[];     // power of two >= the handle's longest truth row (launch_auc)
     __shared__ unsigned long long red[AUC_BLOCK / 64];
     const int64_t i = blockIdx.x;
     const int u = user_ids[i];
@@ -113,9 +113,12 @@ __global__ __launch_bounds__(AUC_BLOCK) void auc_kernel(const float *scores, int
 
 int launch_auc(const float *scores, int64_t ld, const int32_t *user_ids, int64_t n, int n_items,
                const int64_t *ex_ptr, const int32_t *ex_idx, int64_t ex_rows, const int64_t *tr_ptr,
-               const int32_t *tr_idx, int64_t tr_rows, double *out, hipStream_t stream)
+               const int32_t *tr_idx, int64_t tr_rows, int max_pos, double *out, hipStream_t stream)
 {
-    hipLaunchKernelGGL(auc_kernel, dim3((unsigned)n), dim3(AUC_BLOCK), 0, stream, scores, ld, user_ids, n_items, ex_ptr,
+    if (max_pos > AUC_MAX_POS) return -1;
+    int cap = 64;                                   // short truth rows leave LDS for more resident workgroups
+    while (cap < max_pos) cap <<= 1;
+    hipLaunchKernelGGL(auc_kernel, dim3((unsigned)n), dim3(AUC_BLOCK), sizeof(float) * cap, stream, scores, ld, user_ids, n_items, ex_ptr,
                        ex_idx, ex_rows, tr_ptr, tr_idx, tr_rows, out);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
