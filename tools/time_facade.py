@@ -24,3 +24,11 @@ pr = cProfile.Profile(); pr.enable()
 ranking_eval(model, mets, train_set, test_set, verbose=False); torch.cuda.synchronize()
 pr.disable()
 pstats.Stats(pr).sort_stats("cumulative").print_stats(28)
+for name, ms in [("list metrics [NDCG(-1), Recall(100), MRR, MAP]", [M.NDCG(k=-1), M.Recall(k=100), M.MRR(), M.MAP()]),
+                 ("AUC + NDCG@10", [M.AUC(), M.NDCG(k=10)])]:
+    for rep in range(2):
+        t = time.perf_counter()
+        avg, _ = ranking_eval(model, ms, train_set, test_set, verbose=False)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t
+    print(f"{name}: {dt:.3f} s  {nu/dt/1e6:.2f} M users/s  avg {[round(a, 6) for a in avg]}", flush=True)
