@@ -769,8 +769,8 @@ static int sum_columns(ifr_handle h, const double *per_user, const int32_t *eval
     const int grid = (int)((n + ifr::COLSUM_ROWS - 1) / ifr::COLSUM_ROWS);
     int rc = grow(h, &h->ws_met, &h->ws_met_bytes, sizeof(double) * (size_t)grid * (ncol + 1));
     if (rc) return rc;
-    hipLaunchKernelGGL(ifr::colsum_kernel, dim3(grid), dim3(64), 0, s, per_user, evaluated, n, ncol, (double *)h->ws_met);
-    hipLaunchKernelGGL(ifr::reduce_sums_kernel, dim3(1), dim3(64), 0, s, (const double *)h->ws_met, grid, ncol + 1, out_sums);
+    hipLaunchKernelGGL(ifr::colsum_kernel, dim3(grid), dim3(ifr::COLSUM_BLOCK), 0, s, per_user, evaluated, n, ncol, (double *)h->ws_met);
+    hipLaunchKernelGGL(ifr::reduce_sums_kernel, dim3(1), dim3(ifr::COLSUM_BLOCK), 0, s, (const double *)h->ws_met, grid, ncol + 1, out_sums);
     IFR_HIP(h, hipGetLastError());
     return IFR_OK;
 }

@@ -956,28 +956,48 @@ __global__ __launch_bounds__(BLOCK) void pad_rows_min_kernel(float *scores, int6
     for (int c = n_known + threadIdx.x; c < n_cat; c += BLOCK) row[c] = m;
 }
 
-// column sums over evaluated users, two deterministic stages
-constexpr int COLSUM_ROWS = 256;
-__global__ __launch_bounds__(64) void colsum_kernel(const double *per_user, const int32_t *evaluated, int64_t n, int ncol,
-                                                    double *block_sums)
+// column sums over evaluated users, two deterministic stages (fixed assignment of rows to threads and fixed
+// butterfly order, so the fp64 sums do not depend on scheduling)
+constexpr int COLSUM_ROWS = 1024;
+constexpr int COLSUM_BLOCK = 256;
+
+// sum over the 256 threads of a block, identical in every thread of wave 0; `red` holds one slot per wave
+__device__ __forceinline__ double block_sum_256(double v, double *red)
 {
-    const int c = threadIdx.x;
-    const int64_t r0 = (int64_t)blockIdx.x * COLSUM_ROWS;
-    const int64_t r1 = min(r0 + COLSUM_ROWS, n);
-    if (c > ncol) return;
-    double v = 0.0;
-    for (int64_t r = r0; r < r1; ++r)
-        if (evaluated[r]) v += (c < ncol) ? per_user[r * ncol + c] : 1.0;
-    block_sums[(int64_t)blockIdx.x * (ncol + 1) + c] = v;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    const double t = (red[0] + red[1]) + (red[2] + red[3]);
+    __syncthreads();
+    return t;
 }
 
-__global__ void reduce_sums_kernel(const double *block_sums, int n_blocks, int ncol1, double *out)
+__global__ __launch_bounds__(COLSUM_BLOCK) void colsum_kernel(const double *per_user, const int32_t *evaluated, int64_t n, int ncol,
+                                                              double *block_sums)
 {
-    const int c = threadIdx.x;
-    if (c >= ncol1) return;
-    double v = 0.0;
-    for (int b = 0; b < n_blocks; ++b) v += block_sums[(int64_t)b * ncol1 + c];
-    out[c] = v;
+    __shared__ double red[COLSUM_BLOCK / 64];
+    const int64_t r0 = (int64_t)blockIdx.x * COLSUM_ROWS;
+    for (int c = 0; c <= ncol; ++c) {                     // column ncol = the count of evaluated users
+        double v = 0.0;
+        for (int k = 0; k < COLSUM_ROWS / COLSUM_BLOCK; ++k) {
+            const int64_t r = r0 + k * COLSUM_BLOCK + threadIdx.x;
+            if (r < n && evaluated[r]) v += (c < ncol) ? per_user[r * ncol + c] : 1.0;
+        }
+        v = block_sum_256(v, red);
+        if (threadIdx.x == 0) block_sums[(int64_t)blockIdx.x * (ncol + 1) + c] = v;
+    }
+}
+
+__global__ __launch_bounds__(COLSUM_BLOCK) void reduce_sums_kernel(const double *block_sums, int n_blocks, int ncol1, double *out)
+{
+    __shared__ double red[COLSUM_BLOCK / 64];
+    for (int c = 0; c < ncol1; ++c) {
+        double v = 0.0;
+        for (int b = threadIdx.x; b < n_blocks; b += COLSUM_BLOCK) v += block_sums[(int64_t)b * ncol1 + c];
+        v = block_sum_256(v, red);
+        if (threadIdx.x == 0) out[c] = v;
+    }
 }
 
 }  // namespace ifr
