@@ -486,35 +486,51 @@ __global__ __launch_bounds__(BLOCK, 2) void score_dense_kernel(DenseParams p)
     if (t0 < t1) { stage_load(t0); stage_store(0); }
     __syncthreads();
 
-    for (int t = t0; t < t1; ++t) {
+    // row bases of the 16 accumulator rows (null for rows past the batch): one 64-bit add per store
+    float *orow[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int64_t sl = slot0 + acc_row(r, h);
+        orow[r] = sl < p.n ? p.out + sl * p.ld : nullptr;
+    }
+    // Software pipeline over two alternating accumulators: iteration t issues the 64 MFMAs of tile t, then
+    // adds the bases to and stores tile t - 1 while they execute (same scheme as the fused kernel).
+    f32x16 accA = {0}, accB = {0};
+    float ibA = 0.0f, ibB = 0.0f;
+    auto tile_step = [&](int t, f32x16 &accC, float &ibC, const f32x16 &accP, float ibP) {
         const int buf = (t - t0) & 1;
-        if (t + 1 < t1) stage_load(t + 1);
-        f32x16 acc = {0};
-        const float *vrow = &vt[buf][j][4 * h];
+        if (t < t1) {
+            if (t + 1 < t1) stage_load(t + 1);
+            const float *vrow = &vt[buf][j][4 * h];
+            f32x16 acc = {0};
 #pragma unroll
-        for (int g = 0; g < KD / 8; ++g) {
-            const f32x4 b4 = *reinterpret_cast<const f32x4 *>(vrow + 8 * g);
-            // A = user fragment, B = item fragment: D[user row][item col]; the products and
-            // the chain order are the ones of the fused kernel (item*user, k0 then k1).
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ureg[g][0], b4[0], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ureg[g][1], b4[1], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ureg[g][2], b4[2], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ureg[g][3], b4[3], acc, 0, 0, 0);
+            for (int g = 0; g < KD / 8; ++g) {
+                const f32x4 b4 = *reinterpret_cast<const f32x4 *>(vrow + 8 * g);
+                // A = user fragment, B = item fragment: D[user row][item col]; the products and
+                // the chain order are the ones of the fused kernel (item*user, k0 then k1).
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ureg[g][0], b4[0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ureg[g][1], b4[1], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ureg[g][2], b4[2], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ureg[g][3], b4[3], acc, 0, 0, 0);
+            }
+            accC = acc;
+            ibC = HAS_BASE ? vt[buf][j][KD] : 0.0f;
         }
-        const int item = t * TILE_I + j;
-        const float ib = HAS_BASE ? vt[buf][j][KD] : 0.0f;
-        if (item < p.n_items) {
+        if (t > t0) {                                    // tile t - 1
+            const int item = (t - 1) * TILE_I + j;
+            if (item < p.n_items) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int64_t sl = slot0 + acc_row(r, h);
-                if (sl < p.n) {
-                    const float sc = HAS_BASE ? ((ib + ubr[r]) + acc[r]) : acc[r];
-                    p.out[sl * p.ld + item] = sc;
+                for (int r = 0; r < 16; ++r) {
+                    if (orow[r] != nullptr) orow[r][item] = HAS_BASE ? ((ibP + ubr[r]) + accP[r]) : accP[r];
                 }
             }
         }
         if (t + 1 < t1) stage_store(buf ^ 1);
         __syncthreads();
+    };
+    for (int t = t0; t <= t1; t += 2) {                  // one step past the end drains the last tile
+        tile_step(t, accA, ibA, accB, ibB);
+        if (t + 1 <= t1) tile_step(t + 1, accB, ibB, accA, ibA);
     }
 }
 
