@@ -115,7 +115,9 @@ int grow(ifr_handle h, void **p, size_t *have, size_t need)
     return IFR_OK;
 }
 
-int pad_k(int k) { return k <= 32 ? 32 : (k <= 64 ? 64 : (k <= 128 ? 128 : 256)); }
+// factor dimension of the kernel instantiation: 32 / 64 / 128, then steps of 32 up to 256 (the reference's WMF
+// default k = 200 runs as 224)
+int pad_k(int k) { return k <= 32 ? 32 : (k <= 64 ? 64 : (k <= 128 ? 128 : (k + 31) / 32 * 32)); }
 
 void pick_chunks(ifr_handle h, int64_t n, int *chunk_tiles, int *n_chunks)
 {
@@ -141,6 +143,9 @@ void launch_topk_kd(int KD, bool has_base, const ifr::TopkParams &p, int grid, h
     if (KD == 32) launch_topk<32, KL>(has_base, p, grid, s);
     else if (KD == 64) launch_topk<64, KL>(has_base, p, grid, s);
     else if (KD == 128) launch_topk<128, KL>(has_base, p, grid, s);
+    else if (KD == 160) launch_topk<160, KL>(has_base, p, grid, s);
+    else if (KD == 192) launch_topk<192, KL>(has_base, p, grid, s);
+    else if (KD == 224) launch_topk<224, KL>(has_base, p, grid, s);
     else launch_topk<256, KL>(has_base, p, grid, s);
 }
 
@@ -895,6 +900,9 @@ int ifr_score_dense(ifr_handle h, const int32_t *user_ids, int64_t n, float *out
     if (h->KD == 32) launch_dense<32>(h->has_base, p, (int)grid, s);
     else if (h->KD == 64) launch_dense<64>(h->has_base, p, (int)grid, s);
     else if (h->KD == 128) launch_dense<128>(h->has_base, p, (int)grid, s);
+    else if (h->KD == 160) launch_dense<160>(h->has_base, p, (int)grid, s);
+    else if (h->KD == 192) launch_dense<192>(h->has_base, p, (int)grid, s);
+    else if (h->KD == 224) launch_dense<224>(h->has_base, p, (int)grid, s);
     else launch_dense<256>(h->has_base, p, (int)grid, s);
     IFR_HIP(h, hipGetLastError());
     return IFR_OK;
