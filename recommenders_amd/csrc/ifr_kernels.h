@@ -1,7 +1,7 @@
 // ifr_kernels.h -- CDNA4 (gfx950) kernels of the scoring + ranking-evaluation path.
 //
 // Layout in HBM (owned by the handle, see ifr_api.hip):
-//   U      [n_users][KD]        fp32, KD = k padded to 32/64/128 with zeros
+//   U      [n_users][KD]        fp32, KD = k padded to 32/64/128/160/192/224/256 with zeros
 //   V      [n_tiles*32 + 32][KD] fp32, zero rows past n_items (one spare tile so the
 //                                prefetch of "tile + 1" never leaves the allocation)
 //   ibase  [n_tiles*32 + 32]    fp32 item-side base (bias), zeros if the model has none
