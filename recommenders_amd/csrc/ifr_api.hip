@@ -115,9 +115,9 @@ int grow(ifr_handle h, void **p, size_t *have, size_t need)
     return IFR_OK;
 }
 
-// factor dimension of the kernel instantiation: 32 / 64 / 128, then steps of 32 up to 256 (the reference's WMF
-// default k = 200 runs as 224)
-int pad_k(int k) { return k <= 32 ? 32 : (k <= 64 ? 64 : (k <= 128 ? 128 : (k + 31) / 32 * 32)); }
+// factor dimension of the kernel instantiation: steps of 32 up to 256 (the reference's WMF default k = 200 runs
+// as 224, k = 100 as 128, k = 50 as 64)
+int pad_k(int k) { return k <= 32 ? 32 : (k + 31) / 32 * 32; }
 
 void pick_chunks(ifr_handle h, int64_t n, int *chunk_tiles, int *n_chunks)
 {
@@ -142,6 +142,7 @@ void launch_topk_kd(int KD, bool has_base, const ifr::TopkParams &p, int grid, h
 {
     if (KD == 32) launch_topk<32, KL>(has_base, p, grid, s);
     else if (KD == 64) launch_topk<64, KL>(has_base, p, grid, s);
+    else if (KD == 96) launch_topk<96, KL>(has_base, p, grid, s);
     else if (KD == 128) launch_topk<128, KL>(has_base, p, grid, s);
     else if (KD == 160) launch_topk<160, KL>(has_base, p, grid, s);
     else if (KD == 192) launch_topk<192, KL>(has_base, p, grid, s);
@@ -899,6 +900,7 @@ int ifr_score_dense(ifr_handle h, const int32_t *user_ids, int64_t n, float *out
     hipStream_t s = (hipStream_t)stream;
     if (h->KD == 32) launch_dense<32>(h->has_base, p, (int)grid, s);
     else if (h->KD == 64) launch_dense<64>(h->has_base, p, (int)grid, s);
+    else if (h->KD == 96) launch_dense<96>(h->has_base, p, (int)grid, s);
     else if (h->KD == 128) launch_dense<128>(h->has_base, p, (int)grid, s);
     else if (h->KD == 160) launch_dense<160>(h->has_base, p, (int)grid, s);
     else if (h->KD == 192) launch_dense<192>(h->has_base, p, (int)grid, s);

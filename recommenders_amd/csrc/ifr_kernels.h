@@ -1,7 +1,7 @@
 // ifr_kernels.h -- CDNA4 (gfx950) kernels of the scoring + ranking-evaluation path.
 //
 // Layout in HBM (owned by the handle, see ifr_api.hip):
-//   U      [n_users][KD]        fp32, KD = k padded to 32/64/128/160/192/224/256 with zeros
+//   U      [n_users][KD]        fp32, KD = k padded to 32, 64, 96, ... 256 with zeros
 //   V      [n_tiles*32 + 32][KD] fp32, zero rows past n_items (one spare tile so the
 //                                prefetch of "tile + 1" never leaves the allocation)
 //   ibase  [n_tiles*32 + 32]    fp32 item-side base (bias), zeros if the model has none
@@ -256,8 +256,8 @@ __global__ __launch_bounds__(BLOCK, KD > 128 ? 1 : 2) void score_topk_kernel(Top
         // registers of tile t-1: bias add and a running max per 4-register group.  sched_barrier(0) keeps the
         // steps apart so this VALU work issues while the step's last MFMA is still in the pipe.
         constexpr int G = KD / 8;               // k-groups per tile
-        constexpr int SEL_G = G < 16 ? G : 16;  // k-groups that carry select work (KD = 256: the first 16)
-        constexpr int RPG = 16 / SEL_G;         // score registers selected per such k-group
+        constexpr int SEL_G = G < 16 ? G : 16;  // k-groups that carry select work (KD > 128: the first 16)
+        // score registers [16g / SEL_G, 16(g + 1) / SEL_G) are selected in k-group g (KD = 96: 1, 1, 2, 1, 1, 2, ...)
         accN = f32x16{0};
         const float *arow = &vt[buf][j][4 * h];
         const float seltau = (t > t0 && (p.dbg & 7) < 2) ? tau : INFINITY;
@@ -280,7 +280,7 @@ __global__ __launch_bounds__(BLOCK, KD > 128 ? 1 : 2) void score_topk_kernel(Top
             accN = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[2], ureg[g][2], accN, 0, 0, 0);
             accN = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[3], ureg[g][3], accN, 0, 0, 0);
 #pragma unroll
-            for (int r = g * RPG; r < (g < SEL_G ? (g + 1) * RPG : 0); ++r) {
+            for (int r = g * 16 / SEL_G; r < (g < SEL_G ? (g + 1) * 16 / SEL_G : 0); ++r) {
                 const float sc = HAS_BASE ? ((ibC[r] + ub) + accC[r]) : accC[r]; // (ibase + ubase) + dot
                 s[r] = sc;
                 if ((r & 3) == 3)                                               // max of each 4-register group

@@ -48,7 +48,8 @@ def _oracle(w, users, ks, kmax, kperm, want_auc=False):
 
 @pytest.mark.parametrize("k,bias,K", [(128, False, 10), (50, True, 10), (10, True, 5), (128, True, 20), (64, False, 32),
                                       (200, False, 10), (256, True, 20),    # 200 = the reference's WMF default k
-                                      (150, True, 10), (180, False, 20)])   # the 160 / 192 / 224-wide instantiations
+                                      (150, True, 10), (180, False, 20),    # the 160 / 192 / 224-wide instantiations
+                                      (80, True, 10), (96, False, 32)])     # 96-wide
 def test_topk_bit_exact_vs_oracle(torch, k, bias, K):
     w = _workload(1000 + k + K, 777, 3001, k, bias)
     sc = _scorer(w)
