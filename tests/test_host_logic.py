@@ -281,3 +281,20 @@ def test_eval_csrs_are_memoised_per_split_and_notice_edits():
     assert d[0] is not a[0]
     ref2 = ev.build_eval_csrs(tr, te, None, 3.0, 40, 50)
     assert (d[0] != ref2[0]).nnz == 0 and (d[1] != ref2[1]).nnz == 0
+
+
+def test_list_metrics_fall_back_to_sorted_lists_for_very_long_truth_rows(toy, monkeypatch):
+    """Rows with more positives than ifr_eval_dense_metrics holds in LDS take ifr_rank_full + ifr_eval_ranked_metrics;
+    both routes give the same values."""
+    d = toy
+    train_set, test_set, val_set = _datasets(d)
+    mets = [M.NDCG(k=-1), M.Recall(k=50), M.MRR(), M.MAP()]
+    kw = dict(rating_threshold=float(d["rating_threshold"]))
+    a_avg, a_usr = ifr_eval.ranking_eval(types.SimpleNamespace(is_fitted=True), mets, train_set, test_set, val_set,
+                                         _engine=_engine(d, "bpr", test_set.num_users), **kw)
+    monkeypatch.setattr(ifr_eval, "MAX_DENSE_METRIC_POS", 0)
+    eng = _engine(d, "bpr", test_set.num_users)
+    eng.eval_dense_metrics = None                      # must not be called on this route
+    b_avg, b_usr = ifr_eval.ranking_eval(types.SimpleNamespace(is_fitted=True), mets, train_set, test_set, val_set, _engine=eng, **kw)
+    np.testing.assert_allclose(a_avg, b_avg, rtol=0, atol=1e-12)
+    assert a_usr[3] == pytest.approx(b_usr[3], abs=1e-12)
