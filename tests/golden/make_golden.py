@@ -96,6 +96,7 @@ def import_reference(scratch):
     ns.BaseMethod = importlib.import_module("cornac.eval_methods").BaseMethod
     met = importlib.import_module("cornac.metrics")
     ns.NDCG, ns.Recall, ns.Precision, ns.AUC = met.NDCG, met.Recall, met.Precision, met.AUC
+    ns.MRR, ns.MAP, ns.NCRR, ns.HitRatio, ns.FMeasure = met.MRR, met.MAP, met.NCRR, met.HitRatio, met.FMeasure
     ns.fast_dot = u.fast_dot
     return ns
 
@@ -129,6 +130,16 @@ def metric_list(ns, spec):
             out.append(ns.Precision(k=k))
         elif name == "auc":
             out.append(ns.AUC())
+        elif name == "mrr":
+            out.append(ns.MRR())
+        elif name == "map":
+            out.append(ns.MAP())
+        elif name == "ncrr":
+            out.append(ns.NCRR(k=k))
+        elif name == "hit":
+            out.append(ns.HitRatio(k=k))
+        elif name == "f1":
+            out.append(ns.FMeasure(k=k))
     return out
 
 
@@ -270,6 +281,30 @@ def make_unknowns(ns):
     save("unknowns_mf_bpr.npz", out)
 
 
+def make_list_metrics(ns):
+    """Cut-offs beyond the fused top-K (k = -1, 50, 100, 200) and the whole-list metrics
+    (MRR, MAP, NCRR, HitRatio, FMeasure): the reference's own per-user values for BPR and
+    EASE on a 260 x 420 split (ranking.py:49-530 through base_method.py:185-310)."""
+    rng = np.random.default_rng(321)
+    data = synth_uir(rng, 260, 420, 9000)
+    rs = ns.RatioSplit(data=data, test_size=0.25, rating_threshold=3.0, seed=321,
+                       exclude_unknowns=True, verbose=False)
+    spec = [("ndcg", -1), ("ndcg", 50), ("ndcg", 100), ("recall", 50), ("recall", 200), ("precision", 50),
+            ("precision", -1), ("mrr", -1), ("map", -1), ("ncrr", -1), ("ncrr", 50), ("hit", 50), ("f1", 50),
+            ("f1", -1), ("recall", 10), ("ndcg", 10)]
+    out = {"metric_names": np.asarray([f"{n}@{k}" for n, k in spec])}
+    pack_split(rs, out)
+    bpr = ns.BPR(k=24, max_iter=30, seed=321)
+    bpr.fit(rs.train_set)
+    out["bpr_U"], out["bpr_V"], out["bpr_Bi"] = bpr.u_factors, bpr.i_factors, bpr.i_biases
+    add_result(out, "bpr", run_eval(ns, bpr, spec, rs, head=8, n_score_users=2))
+    ease = ns.EASE(lamb=30, verbose=False)
+    ease.fit(rs.train_set)
+    out["ease_B"] = ease.B.astype(np.float64)
+    add_result(out, "ease", run_eval(ns, ease, spec, rs, head=8, n_score_users=2))
+    save("list_metrics_bpr_ease.npz", out)
+
+
 def make_fastdot(ns):
     """Outputs of the reference's compiled fast_dot on random fp32/fp64 inputs."""
     rng = np.random.default_rng(11)
@@ -287,15 +322,17 @@ def make_fastdot(ns):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--scratch", default="/tmp/oracle")
+    ap.add_argument("--only", default="", help="comma-separated subset of: fastdot,toy,c1,unknowns,list "
+                    "(BPR's threaded trainer is not run-to-run reproducible, so regenerate only what changed)")
     args = ap.parse_args()
     warnings.filterwarnings("ignore")
     prepare_scratch(args.scratch)
     os.chdir(args.scratch)
     ns = import_reference(args.scratch)
-    make_fastdot(ns)
-    make_toy(ns)
-    make_c1(ns)
-    make_unknowns(ns)
+    makers = {"fastdot": make_fastdot, "toy": make_toy, "c1": make_c1, "unknowns": make_unknowns,
+              "list": make_list_metrics}
+    for name in (args.only.split(",") if args.only else list(makers)):
+        makers[name](ns)
 
 
 if __name__ == "__main__":

@@ -277,3 +277,34 @@ def test_cutoffs_beyond_32_match_the_sorted_list_path(toy):
     got = np.asarray([[per[j][int(u)] for j in range(len(mets))] for u in users])
     np.testing.assert_allclose(got, want, rtol=0, atol=1e-12)
     np.testing.assert_allclose(avg, want.mean(axis=0), rtol=0, atol=1e-12)
+
+
+@pytest.mark.parametrize("name", ["bpr", "ease"])
+def test_list_metrics_match_reference(list_metrics, name):
+    """Cut-offs beyond the fused top-K (50 / 100 / 200), k = -1, MRR, MAP, NCRR, HitRatio, FMeasure -- served by
+    ifr_eval_dense_metrics -- against the per-user values of the reference's own ranking_eval."""
+    from conftest import metric_objects, positives_clear
+    from recommenders_amd.models import EASE
+    d = list_metrics
+    train_set, test_set, _ = _sets(d)
+    if name == "bpr":
+        model = _model(d, "bpr", train_set)
+    else:
+        model = EASE(lamb=30, trainable=False, init_params={"B": d["ease_B"]}).fit(train_set)
+    mets = metric_objects(d["metric_names"])
+    avg, per = ranking_eval(model, mets, train_set, test_set, rating_threshold=float(d["rating_threshold"]),
+                            exclude_unknowns=True)
+    users, ref = d[f"{name}__users"], d[f"{name}__per_user"]
+    assert sorted(per[0].keys()) == users.tolist()
+    clear = []
+    for u in users:
+        u = int(u)
+        cand = model.item_scores_mapped_indices[u]
+        pos = test_set.csr_matrix.getrow(u)
+        pos = pos.indices[pos.data >= float(d["rating_threshold"])]
+        clear.append(positives_clear(np.asarray(model.score(u), np.float64).ravel(), cand, pos))
+    clear = np.asarray(clear)
+    assert clear.mean() > 0.8
+    got = np.asarray([[per[j][int(u)] for j in range(len(mets))] for u in users])
+    np.testing.assert_allclose(got[clear], ref[clear], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(avg, d[f"{name}__avg"], atol=5e-4, rtol=0)

@@ -148,6 +148,31 @@ def test_ranking_eval_full_list_metrics_and_errors(toy):
         ifr_eval.ranking_eval(fake, [M.NDCG(k=10)], train_set, empty, _engine=eng)
 
 
+def test_list_metrics_host_logic_against_reference(list_metrics):
+    """k = -1 / 50 / 100 / 200 cut-offs, MRR, MAP, NCRR, HitRatio, FMeasure through ranking_eval's list route:
+    the reference's own per-user values (fixture made by the reference's ranking_eval)."""
+    from conftest import metric_objects, positives_clear
+    d = list_metrics
+    train_set, test_set, _ = _datasets(d)
+    eng = _engine(d, "bpr", test_set.num_users)
+    mets = metric_objects(d["metric_names"])
+    thr, ni = float(d["rating_threshold"]), int(d["num_items"])
+    avg, per = ifr_eval.ranking_eval(types.SimpleNamespace(is_fitted=True), mets, train_set, test_set,
+                                     rating_threshold=thr, exclude_unknowns=True, _engine=eng)
+    users, ref = d["bpr__users"], d["bpr__per_user"]
+    assert sorted(per[0].keys()) == users.tolist()
+    train, test = _csr(d, "train"), _csr(d, "test")
+    clear = []
+    for u in users:
+        cand, pos, _ = orc.eval_sets(train, test, None, int(u), thr, ni, test.shape[1], True)
+        clear.append(positives_clear(orc.score_bpr(d["bpr_U"], d["bpr_V"], d["bpr_Bi"], int(u)), cand, pos))
+    clear = np.asarray(clear)
+    assert clear.mean() > 0.8
+    got = np.asarray([[per[j][int(u)] for j in range(len(mets))] for u in users])
+    np.testing.assert_allclose(got[clear], ref[clear], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(avg, d["bpr__avg"], atol=5e-4, rtol=0)
+
+
 def test_plan_metrics_and_names():
     specs, ks, need_auc, need_list = ifr_eval.plan_metrics([M.NDCG(k=10), M.Recall(k=10), M.Precision(k=5)])
     assert specs == [("ndcg", 10), ("recall", 10), ("precision", 5)] and ks == [5, 10] and not need_auc and not need_list

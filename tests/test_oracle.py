@@ -200,6 +200,33 @@ def test_unknowns_against_reference(unknowns, model):
     _check_against_reference(unknowns, model, 2e-5)
 
 
+@pytest.mark.parametrize("model,tol", [("bpr", 2e-5), ("ease", 1e-9)])
+def test_list_metrics_against_reference(list_metrics, model, tol):
+    """NDCG / Recall / Precision / NCRR / FMeasure at k = -1 and beyond the fused top-K, HitRatio@50, MRR, MAP:
+    per-user values of the reference's ranking_eval (ranking.py:49-530) for every user whose positives are not
+    in a near-tie."""
+    from conftest import positives_clear
+    d = list_metrics
+    _check_against_reference(d, model, tol)
+    spec = _spec(d)
+    train, test = _csr(d, "train"), _csr(d, "test")
+    fn = _score_fn(d, model)
+    thr, ni = float(d["rating_threshold"]), int(d["num_items"])
+    avg, per, _ = orc.ranking_eval(fn, spec, train, test, None, rating_threshold=thr, exclude_unknowns=True,
+                                   n_train_items=ni, n_test_items=int(d["total_items"]))
+    users, ref = d[f"{model}__users"], d[f"{model}__per_user"]
+    n_clear = 0
+    for r, u in enumerate(users):
+        cand, pos, _ = orc.eval_sets(train, test, None, int(u), thr, ni, int(d["total_items"]), True)
+        if not positives_clear(fn(int(u)), cand, pos):
+            continue
+        n_clear += 1
+        got = np.asarray([per[m][int(u)] for m in range(len(spec))])
+        np.testing.assert_allclose(got, ref[r], rtol=0, atol=1e-9, err_msg=f"user {u}")
+    assert n_clear >= 0.8 * len(users)
+    np.testing.assert_allclose(avg, d[f"{model}__avg"], atol=5e-4, rtol=0)
+
+
 # ----------------------------------------------------------------- C twin == numpy restatement
 def test_c_twin_matches_numpy(toy):
     d = toy
