@@ -127,7 +127,7 @@ __global__ __launch_bounds__(BLOCK, KD > 128 ? 1 : 2) void score_topk_kernel(Top
     static_assert((TILE_I * C4) % BLOCK == 0, "tile must split evenly");
     __shared__ __attribute__((aligned(16))) float vt[2][TILE_I][ROW];
     __shared__ __attribute__((aligned(16))) float ibt[2][TILE_I];
-    __shared__ uint2 pend[PEND][BLOCK];
+    __shared__ uint2 pend[PEND + 1][BLOCK];      // row PEND: dump row of the straight-line append
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -263,7 +263,8 @@ __global__ __launch_bounds__(BLOCK, KD > 128 ? 1 : 2) void score_topk_kernel(Top
         const float seltau = (t > t0 && (p.dbg & 7) < 2) ? tau : INFINITY;
         const int item0 = (t - 1) * TILE_I + 4 * h;
         const uint32_t mm = mC >> (4 * h);
-        float s[16], gmx[4], ibC[16];
+        float s[16], ibC[16];
+        unsigned long long hb[16];              // per score register: ballot of the lanes whose score passes (SGPR pairs)
         f32x4 a_cur = *reinterpret_cast<const f32x4 *>(arow);
 #pragma unroll
         for (int g = 0; g < G; ++g) {
@@ -283,35 +284,34 @@ __global__ __launch_bounds__(BLOCK, KD > 128 ? 1 : 2) void score_topk_kernel(Top
             for (int r = g * 16 / SEL_G; r < (g < SEL_G ? (g + 1) * 16 / SEL_G : 0); ++r) {
                 const float sc = HAS_BASE ? ((ibC[r] + ub) + accC[r]) : accC[r]; // (ibase + ubase) + dot
                 s[r] = sc;
-                if ((r & 3) == 3)                                               // max of each 4-register group
-                    gmx[r >> 2] = max3_raw(max3_raw(s[r - 3], s[r - 2], s[r - 1]), sc, sc);
+                hb[r] = __ballot(sc > seltau);                                  // one v_cmp into an SGPR pair
             }
             a_cur = a_nxt;
             __builtin_amdgcn_sched_barrier(0);
         }
         if (dbg_stamp) T2 = __builtin_amdgcn_s_memtime();
 
-        // ---- zone B: threshold vote; only groups (4 registers) that hold a hit are scanned
-        const float mx = max3_raw(max3_raw(gmx[0], gmx[1], gmx[2]), gmx[3], gmx[3]);
+        // ---- zone B: only score registers in which some lane hits are visited, behind wave-uniform scalar
+        // branches on the ballots of zone A (a hit tile used to scan every 4-register group that held a hit)
         unsigned long long T2b = 0, T2c = 0;
-        if (__any(mx > seltau)) {
+        unsigned long long hany = 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) hany |= hb[r];
+        if (hany != 0) {
             uint32_t todo = 0;                  // hits that found the lane's pending slots full
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                if (gmx[q] > seltau) {
-#pragma unroll
-                    for (int r = 4 * q; r < 4 * q + 4; ++r) {
-                        // exclusions (and rows past n_items) are dropped here, on the rare path: the
-                        // fp32 MFMA shares the VALU, so a per-score kill in zone A is paid on every tile
-                        if (s[r] > seltau && !((mm >> ((r & 3) + 8 * q)) & 1u)) {
-                            if (cnt < PEND) {
-                                pend[cnt][tid] = make_uint2(__float_as_uint(s[r]), (uint32_t)(item0 + (r & 3) + 8 * q));
-                                ++cnt;
-                            } else {
-                                todo |= 1u << r;
-                            }
-                        }
-                    }
+            for (int r = 0; r < 16; ++r) {
+                if (hb[r] != 0) {
+                    asm volatile("" ::: "memory");   // keeps this a block of its own behind a scalar branch
+                    // Straight-line append: a lane that does not hit (or has no free slot) writes the dump row
+                    // pend[PEND] instead of being masked off -- no exec-mask juggling per score register.
+                    // Exclusions (and rows past n_items) are dropped here, on the rare path: the fp32 MFMA
+                    // shares the VALU, so a per-score kill in zone A is paid on every tile.
+                    const bool hit = (s[r] > seltau) & !((mm >> ((r & 3) + 8 * (r >> 2))) & 1u);
+                    const bool ok = hit & (cnt < PEND);
+                    pend[ok ? cnt : PEND][tid] = make_uint2(__float_as_uint(s[r]), (uint32_t)(item0 + (r & 3) + 8 * (r >> 2)));
+                    cnt += ok ? 1 : 0;
+                    todo |= (hit & !ok) ? (1u << r) : 0u;
                 }
             }
             if (dbg_stamp) T2b = __builtin_amdgcn_s_memtime();
