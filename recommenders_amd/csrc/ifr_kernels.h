@@ -253,7 +253,7 @@ __global__ __launch_bounds__(BLOCK, KD > 128 ? 1 : 2) void score_topk_kernel(Top
 
         // ---- zone A: 32 items x 32 users x KD on the matrix core (tile t), one k-group of four
         // MFMAs per step, each step followed by the branch-free part of the select for 128/KD score
-        // registers of tile t-1: bias add and a running max per 4-register group.  sched_barrier(0) keeps the
+        // registers of tile t-1: bias add and the threshold compare (its ballot lands in SGPRs).  sched_barrier(0) keeps the
         // steps apart so this VALU work issues while the step's last MFMA is still in the pipe.
         constexpr int G = KD / 8;               // k-groups per tile
         constexpr int SEL_G = G < 16 ? G : 16;  // k-groups that carry select work (KD > 128: the first 16)
