@@ -160,6 +160,60 @@ def cache_rankings(model, user_idx, item_indices, k=-1):
     return item_rank, item_scores
 
 
+def export_candidate_pools(model, pool_size, batch_users=1 << 16, _engine=None):
+    """Heads of the cached rankings for the re-ranking stage: the re-rankers keep only the first `pool_size`
+    ranked items of a user (rerankers/reranker.py:620-639) and look their scores up through
+    `item_scores_mapped_indices` (static_rerank_evaluator.py:262-296), so the hand-off needs
+    pool_size ids + pool_size scores per user, not three catalogue-long arrays.
+
+    Returns three plain dicts shaped like `model.ranked_items / item_scores / item_scores_mapped_indices`
+    for every user the last `ranking_eval` calls cached, with the candidate sets those evaluations used:
+    ranked_items[u] = the first pool_size items of the full ranking (canonical tie order),
+    item_scores[u][j] = score of item_scores_mapped_indices[u][j], and the mapping is that same head.
+    Lazy users are ranked in batches by the fused / select top-K kernels; users whose full ranking was
+    already materialised, or who have fewer known candidates than pool_size, are cut from the full ranking."""
+    import torch
+    from .engine import MAX_SELECT_TOPK
+    owner = getattr(model, "_hip_cache_owner", None)
+    if owner is None:
+        raise RuntimeError("export_candidate_pools: no cached evaluation on this model, call ranking_eval first")
+    pool_size = int(pool_size)
+    if pool_size <= 0 or pool_size > MAX_SELECT_TOPK:
+        raise ValueError(f"pool_size must be in 1..{MAX_SELECT_TOPK} (use the full caches beyond that)")
+    eng = model._hip_engine() if _engine is None else _engine
+    ranked_out, scores_out, mapped_out = {}, {}, {}
+
+    def from_full(u):
+        ranked = np.asarray(model.ranked_items[u])                  # materialises a lazy user
+        lut_items = np.asarray(model.item_scores_mapped_indices[u])
+        lut_scores = np.asarray(model.item_scores[u])
+        head = ranked[:pool_size]
+        order = np.argsort(lut_items, kind="stable")
+        pos = order[np.searchsorted(lut_items[order], head)]
+        ranked_out[u], scores_out[u], mapped_out[u] = head, lut_scores[pos], head.copy()
+
+    explicit = getattr(model.ranked_items, "_explicit", {})
+    lazy = np.asarray([int(u) for u in owner.users if int(u) not in explicit], np.int64)
+    for u in explicit:
+        from_full(int(u))
+    if len(lazy):
+        eng.set_catalogue_items(owner.n_items)
+        excl = owner.excl
+        eng.set_exclusion_csr(excl.indptr.astype(np.int64), excl.indices.astype(np.int32))
+        k = min(pool_size, eng.n_items)
+        for lo in range(0, len(lazy), int(batch_users)):
+            part = lazy[lo:lo + int(batch_users)]
+            ids, sc = eng.rank_topk(torch.as_tensor(part.astype(np.int32), device=eng.device), k)
+            ids, sc = ids.cpu().numpy(), sc.cpu().numpy()
+            for r, u in enumerate(part.tolist()):
+                if (ids[r] < 0).any() or k < pool_size:
+                    from_full(u)                                   # short list: unknown items may follow the known ones
+                else:
+                    head = ids[r].astype(np.int64)
+                    ranked_out[u], scores_out[u], mapped_out[u] = head, sc[r].copy(), head.copy()
+    return ranked_out, scores_out, mapped_out
+
+
 # --------------------------------------------------------------------------- metric plan
 def plan_metrics(metrics):
     """-> (specs, fused_ks, list_ks, need_auc, need_list).  specs[i] = (kind, k) of metrics[i]."""

@@ -88,6 +88,32 @@ class RecommenderBase:
     def default_score(self):
         return self.global_mean
 
+    def save_recommendations(self, save_dir, pool_size=None):
+        """recommender.py:244-274: the three caches as `recommendations.pkl`, `item_scores.pkl` and
+        `item_scores_mapped_indices.pkl` under save_dir (plain dicts user index -> array).
+
+        pool_size=None writes what the reference writes: every cached user's full ranking and full score
+        vector (the lazy caches materialise every user for it).  pool_size=P writes the heads only --
+        P ranked items, their scores and the matching index arrays -- which is all the re-ranking stage
+        reads (rerankers/reranker.py:620-639) and stays small at any catalogue size
+        (`recommenders_amd.eval.export_candidate_pools`)."""
+        import os
+        import pickle
+        os.makedirs(save_dir, exist_ok=True)
+        if pool_size is None or int(pool_size) < 0:
+            parts = (dict(self.ranked_items.items()), dict(self.item_scores.items()),
+                     dict(self.item_scores_mapped_indices.items()))
+        else:
+            from .eval import export_candidate_pools
+            parts = export_candidate_pools(self, pool_size)
+        names = ("recommendations.pkl", "item_scores.pkl", "item_scores_mapped_indices.pkl")
+        for name, part in zip(names, parts):
+            with open(os.path.join(save_dir, name), "wb") as f:
+                pickle.dump(part, f)
+        if self.verbose:
+            print(f"Recommendations, item scores and their index maps saved to {save_dir}")
+        return [os.path.join(save_dir, n) for n in names]
+
     def recommend(self, user_id, k=-1, remove_seen=False, train_set=None):
         """recommender.py:708-756."""
         user_idx = self.uid_map.get(user_id, -1)

@@ -308,3 +308,34 @@ def test_list_metrics_match_reference(list_metrics, name):
     got = np.asarray([[per[j][int(u)] for j in range(len(mets))] for u in users])
     np.testing.assert_allclose(got[clear], ref[clear], rtol=0, atol=1e-9)
     np.testing.assert_allclose(avg, d[f"{name}__avg"], atol=5e-4, rtol=0)
+
+
+def test_save_recommendations_full_and_pooled(toy, tmp_path):
+    """Recommender.save_recommendations (recommender.py:244-274): the reference's three pickle files; with
+    pool_size the heads only (what the re-rankers read), batched on the GPU, equal to the heads of the full files
+    and to the reference's own ranked heads."""
+    import pickle
+    d = toy
+    train_set, test_set, val_set = _sets(d)
+    model = _model(d, "bpr", train_set)
+    ranking_eval(model, [M.NDCG(k=10)], train_set, test_set, val_set=val_set,
+                 rating_threshold=float(d["rating_threshold"]), exclude_unknowns=True)
+    users = d["bpr__users"]
+    load = lambda path: pickle.load(open(path, "rb"))
+    pooled = [load(f) for f in model.save_recommendations(str(tmp_path / "pool"), pool_size=19)]
+    assert [type(x) for x in pooled] == [dict, dict, dict]
+    assert sorted(pooled[0]) == users.tolist()
+    tf = _tie_free(d, "bpr")
+    for r, u in enumerate(users.tolist()):
+        assert len(pooled[0][u]) == 19 == len(pooled[1][u]) == len(pooled[2][u])
+        np.testing.assert_array_equal(pooled[0][u], pooled[2][u])
+        if tf[r]:
+            np.testing.assert_array_equal(pooled[0][u], d["bpr__ranked_head"][r][:19])
+            np.testing.assert_allclose(pooled[1][u], d["bpr__ranked_head_scores"][r][:19], rtol=1e-5, atol=1e-6)
+    full = [load(f) for f in model.save_recommendations(str(tmp_path / "full"))]
+    assert [type(x) for x in full] == [dict, dict, dict] and sorted(full[0]) == users.tolist()
+    for r, u in enumerate(users.tolist()):
+        assert len(full[0][u]) == d["bpr__n_cand"][r] == len(full[1][u]) == len(full[2][u])
+        np.testing.assert_array_equal(full[0][u][:19], pooled[0][u])
+        lut = dict(zip(full[2][u].tolist(), full[1][u].tolist()))
+        assert [lut[i] for i in pooled[0][u].tolist()] == pooled[1][u].tolist()

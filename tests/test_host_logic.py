@@ -173,6 +173,51 @@ def test_list_metrics_host_logic_against_reference(list_metrics):
     np.testing.assert_allclose(avg, d["bpr__avg"], atol=5e-4, rtol=0)
 
 
+def test_candidate_pools_are_the_heads_of_the_cached_rankings(toy):
+    """export_candidate_pools (the re-ranker hand-off, reranker.py:620-639): pool_size ids + aligned scores per
+    cached user, equal to the head of the full ranking the lazy caches would materialise."""
+    d = toy
+    train_set, test_set, val_set = _datasets(d)
+    eng = _engine(d, "bpr", test_set.num_users)
+
+    class FakeModel:
+        is_fitted = True
+
+        def __init__(self):
+            self.ranked_items, self.item_scores, self.item_scores_mapped_indices = {}, {}, {}
+
+        def rank(self, user_idx, item_indices=None, k=-1):
+            s = orc.score_bpr(d["bpr_U"], d["bpr_V"], d["bpr_Bi"], user_idx).astype(np.float32)
+            cand = np.asarray(item_indices)
+            ranked = orc.canonical_rank(cand, s[cand])
+            self.ranked_items[user_idx], self.item_scores[user_idx] = ranked, s[cand]
+            self.item_scores_mapped_indices[user_idx] = cand
+            return ranked, s[cand]
+
+    model = FakeModel()
+    with pytest.raises(RuntimeError):
+        ifr_eval.export_candidate_pools(model, 10, _engine=eng)
+    ifr_eval.ranking_eval(model, [M.NDCG(k=10)], train_set, test_set, val_set,
+                          rating_threshold=float(d["rating_threshold"]), _engine=eng)
+    users = d["bpr__users"]
+    first = int(users[0])
+    full_first = model.ranked_items[first]                      # one user materialised before the export
+    for pool in (5, 40):
+        ranked, scores, mapped = ifr_eval.export_candidate_pools(model, pool, batch_users=64, _engine=eng)
+        assert sorted(ranked) == users.tolist() == sorted(scores) == sorted(mapped)
+        np.testing.assert_array_equal(ranked[first], full_first[:pool])
+        for u in users[:: max(1, len(users) // 12)]:
+            u = int(u)
+            s = orc.score_bpr(d["bpr_U"], d["bpr_V"], d["bpr_Bi"], u).astype(np.float32)
+            assert len(ranked[u]) == pool == len(scores[u])
+            np.testing.assert_array_equal(mapped[u], ranked[u])
+            np.testing.assert_allclose(scores[u], s[ranked[u]], rtol=1e-6, atol=1e-7)
+            assert (np.diff(scores[u]) <= 0).all()
+    for bad in (0, -3, 5000):
+        with pytest.raises(ValueError):
+            ifr_eval.export_candidate_pools(model, bad, _engine=eng)
+
+
 def test_plan_metrics_and_names():
     specs, ks, need_auc, need_list = ifr_eval.plan_metrics([M.NDCG(k=10), M.Recall(k=10), M.Precision(k=5)])
     assert specs == [("ndcg", 10), ("recall", 10), ("precision", 5)] and ks == [5, 10] and not need_auc and not need_list
