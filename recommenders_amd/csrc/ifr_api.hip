@@ -696,11 +696,9 @@ static int rank_topk_item_item(ifr_handle h, const int32_t *user_ids, int64_t n,
     const size_t smem = (size_t)p.n_chunks * KL * 8;
     if (smem > 60000) return fail(h, IFR_ERR_ARG, "ifr_rank_topk: catalogue too large for the merge kernel");
     if (KL == 16)
-        hipLaunchKernelGGL((ifr::merge_topk_kernel<16>), dim3((unsigned)n), dim3(64), smem, s, p.part_scores, p.part_ids, n,
-                           p.n_chunks, K, out_ids, out_scores);
+        ifr::launch_merge_topk<16>(p.part_scores, p.part_ids, n, p.n_chunks, K, out_ids, out_scores, s);
     else
-        hipLaunchKernelGGL((ifr::merge_topk_kernel<32>), dim3((unsigned)n), dim3(64), smem, s, p.part_scores, p.part_ids, n,
-                           p.n_chunks, K, out_ids, out_scores);
+        ifr::launch_merge_topk<32>(p.part_scores, p.part_ids, n, p.n_chunks, K, out_ids, out_scores, s);
     IFR_HIP(h, hipGetLastError());
     return IFR_OK;
 }
@@ -758,12 +756,11 @@ int ifr_rank_topk(ifr_handle h, const int32_t *user_ids, int64_t n, int K, int32
     }
     IFR_HIP(h, hipGetLastError());
     const size_t smem = (size_t)n_chunks * 2 * KL * 8;
+    if (smem > 60000) return fail(h, IFR_ERR_ARG, "ifr_rank_topk: too many item chunks for the merge kernel");
     if (KL == 16)
-        hipLaunchKernelGGL((ifr::merge_topk_kernel<16>), dim3((unsigned)n), dim3(64), smem, s, p.part_scores, p.part_ids,
-                           n, n_chunks * 2, K, out_ids, out_scores);
+        ifr::launch_merge_topk<16>(p.part_scores, p.part_ids, n, n_chunks * 2, K, out_ids, out_scores, s);
     else
-        hipLaunchKernelGGL((ifr::merge_topk_kernel<32>), dim3((unsigned)n), dim3(64), smem, s, p.part_scores, p.part_ids,
-                           n, n_chunks * 2, K, out_ids, out_scores);
+        ifr::launch_merge_topk<32>(p.part_scores, p.part_ids, n, n_chunks * 2, K, out_ids, out_scores, s);
     IFR_HIP(h, hipGetLastError());
     return IFR_OK;
 }

@@ -416,6 +416,87 @@ __global__ __launch_bounds__(64) void merge_topk_kernel(const float *part_scores
     for (int r = n_valid + lane; r < K; r += 64) { out_ids[u * K + r] = -1; out_scores[u * K + r] = -INFINITY; }
 }
 
+// The same merge for short inputs (n_lists * K <= 64 * NE entries, the usual case: 8 lists x K = 10), without
+// the dependent LDS reads of the binary searches: only the first K entries of a list can reach the top K, each
+// becomes one 64-bit key (order-preserving score bits, then ~id, so "beats" is one unsigned compare; an unfilled
+// slot is key 0), a lane keeps NE keys in registers and counts the keys that beat them in one pass over the
+// wave's key array (every lane reads the same address: an LDS broadcast).  One wave per user, four users per
+// workgroup.
+constexpr int MERGE_WAVES = 4;
+
+template <int KL, int NE>
+__global__ __launch_bounds__(64 * MERGE_WAVES) void merge_pairs_kernel(const float *part_scores, const int32_t *part_ids,
+                                                                       int64_t n, int n_lists, int K,
+                                                                       int32_t *out_ids, float *out_scores)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t u = (int64_t)blockIdx.x * MERGE_WAVES + w;
+    const int E = n_lists * K;                       // <= 64 * NE (host-checked)
+    const int Epad = (E + 7) & ~7;
+    unsigned long long *keys = reinterpret_cast<unsigned long long *>(smem) + (size_t)w * Epad;
+    const bool live = u < n;
+    const float *ps = part_scores + (live ? u : 0) * (int64_t)n_lists * KL;
+    const int32_t *pi = part_ids + (live ? u : 0) * (int64_t)n_lists * KL;
+    unsigned long long k[NE];
+    float sc[NE];
+    int n_valid = 0;
+#pragma unroll
+    for (int q = 0; q < NE; ++q) {
+        const int e = lane + 64 * q;
+        k[q] = 0; sc[q] = 0.0f;
+        if (e < E) {
+            const int l = e / K, i = e - l * K;
+            const int id = pi[l * KL + i];
+            sc[q] = ps[l * KL + i];
+            if (id != NO_TILE) {
+                k[q] = ((unsigned long long)float_to_key(sc[q] + 0.0f) << 32) | (uint32_t)~id;   // + 0: -0 ties with +0
+                ++n_valid;
+            }
+        }
+        if (e < Epad) keys[e] = k[q];
+    }
+    __syncthreads();
+    int rank[NE];
+#pragma unroll
+    for (int q = 0; q < NE; ++q) rank[q] = 0;
+    for (int e = 0; e < Epad; e += 8) {
+        unsigned long long x[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) x[t] = keys[e + t];
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+#pragma unroll
+            for (int q = 0; q < NE; ++q) rank[q] += x[t] > k[q] ? 1 : 0;
+    }
+    if (!live) return;
+#pragma unroll
+    for (int q = 0; q < NE; ++q)
+        if (k[q] != 0 && rank[q] < K) { out_ids[u * K + rank[q]] = (int32_t)~(uint32_t)k[q]; out_scores[u * K + rank[q]] = sc[q]; }
+    // fewer than K candidates: pad the tail
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) n_valid += __shfl_xor(n_valid, off);
+    for (int r = n_valid + lane; r < K; r += 64) { out_ids[u * K + r] = -1; out_scores[u * K + r] = -INFINITY; }
+}
+
+template <int KL>
+inline void launch_merge_topk(const float *part_scores, const int32_t *part_ids, int64_t n, int n_lists, int K,
+                              int32_t *out_ids, float *out_scores, hipStream_t s)
+{
+    const int E = n_lists * K;
+    const unsigned grid4 = (unsigned)((n + MERGE_WAVES - 1) / MERGE_WAVES);
+    const size_t smem4 = (size_t)MERGE_WAVES * ((E + 7) & ~7) * 8;
+    if (E <= 64)
+        hipLaunchKernelGGL((merge_pairs_kernel<KL, 1>), dim3(grid4), dim3(64 * MERGE_WAVES), smem4, s, part_scores, part_ids, n, n_lists, K, out_ids, out_scores);
+    else if (E <= 128)
+        hipLaunchKernelGGL((merge_pairs_kernel<KL, 2>), dim3(grid4), dim3(64 * MERGE_WAVES), smem4, s, part_scores, part_ids, n, n_lists, K, out_ids, out_scores);
+    else if (E <= 256)
+        hipLaunchKernelGGL((merge_pairs_kernel<KL, 4>), dim3(grid4), dim3(64 * MERGE_WAVES), smem4, s, part_scores, part_ids, n, n_lists, K, out_ids, out_scores);
+    else
+        hipLaunchKernelGGL((merge_topk_kernel<KL>), dim3((unsigned)n), dim3(64), (size_t)n_lists * KL * 8, s, part_scores, part_ids, n,
+                           n_lists, K, out_ids, out_scores);
+}
+
 // ------------------------------------------------------------------------------------
 // Dense score rows out[slot][item] for a batch of users (same fma chain as the fused
 // kernel, operand roles swapped so a lane owns an item column and stores are coalesced).
