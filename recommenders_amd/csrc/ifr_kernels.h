@@ -93,15 +93,6 @@ __device__ __forceinline__ void list_insert(float (&ls)[KL], int (&li)[KL], floa
     ls[0] = fmaxf(x, ls[0]);
 }
 
-// max of three without the canonicalising self-max that fmaxf() costs per operand (NaN operands
-// cannot make a finite result larger, and a NaN result never passes the '>' tests that follow)
-__device__ __forceinline__ float max3_raw(float a, float b, float c)
-{
-    float d;
-    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
-    return d;
-}
-
 template <int KL>
 __device__ __forceinline__ float list_tau(const float (&ls)[KL], int K)
 {
