@@ -169,8 +169,12 @@ def main():
     copied = [torch.cuda.Event() for _ in range(2)]
     step_no = [0]
 
-    auc_rows = max(1, min(n, (1 << 28) // w["n_items"])) if args.auc else 0
-    auc_buf = torch.empty((auc_rows, w["n_items"]), dtype=torch.float32, device=dev) if args.auc else None
+    # AUC variant: dot-product models let the fused kernel write the score rows the AUC kernel reads
+    # (ifr_rank_topk_dense, up to a 16 GB buffer per batch of users); item-item models score the rows separately
+    auc_fused = bool(args.auc and sc.can_rank_topk_dense(TOPK))
+    auc_ld = (w["n_items"] + 31) // 32 * 32
+    auc_rows = max(1, min(n, ((1 << 32) if auc_fused else (1 << 28)) // auc_ld)) if args.auc else 0
+    auc_buf = torch.empty((auc_rows, auc_ld), dtype=torch.float32, device=dev) if args.auc else None
     auc_out = torch.empty((n,), dtype=torch.float64, device=dev) if args.auc else None
 
     def step():
@@ -178,12 +182,18 @@ def main():
         step_no[0] += 1
         ids, scores = ids2[buf], scores2[buf]
         torch.cuda.current_stream(dev).wait_event(copied[buf])      # the copy that last read these buffers is done
-        sc.rank_topk(users, TOPK, ids, scores)
-        per_user, evaluated, sums = sc.eval_topk_metrics(users, ids, [TOPK])
-        if args.auc:
+        if auc_fused:
             for b in range(0, n, auc_rows):
                 ub = users[b:b + auc_rows]
-                dense = sc.score_dense(ub, auc_buf[: ub.numel()])
+                _, _, dense = sc.rank_topk_dense(ub, TOPK, auc_buf, ids[b:b + auc_rows], scores[b:b + auc_rows])
+                auc_out[b:b + auc_rows] = sc.auc_dense(ub, dense)
+        else:
+            sc.rank_topk(users, TOPK, ids, scores)
+        per_user, evaluated, sums = sc.eval_topk_metrics(users, ids, [TOPK])
+        if args.auc and not auc_fused:
+            for b in range(0, n, auc_rows):
+                ub = users[b:b + auc_rows]
+                dense = sc.score_dense(ub, auc_buf[: ub.numel(), : w["n_items"]])
                 auc_out[b:b + auc_rows] = sc.auc_dense(ub, dense)
         if world > 1:
             sums = all_reduce(sums)                    # RCCL: per-metric sums + evaluated-user count
@@ -271,7 +281,7 @@ def main():
             "data": "synthetic",
             "config": cfg,
             "roofline": roof,
-            "variant": "top-10 + NDCG/Recall/Precision@10" + (" + AUC (dense rows)" if args.auc else ""),
+            "variant": "top-10 + NDCG/Recall/Precision@10" + ((" + AUC (score rows written by the fused kernel)" if auc_fused else " + AUC (dense rows)") if args.auc else ""),
             "eval": {"ndcg@10": sums[0] / sums[-1], "recall@10": sums[1] / sums[-1],
                      "precision@10": sums[2] / sums[-1], "n_evaluated": float(sums[-1])},
         }

@@ -46,6 +46,8 @@ struct TopkParams {
     float *part_scores;      // [n_slots][n_chunks*2][KL]
     int32_t *part_ids;
     uint32_t *lb;            // [n_slots padded to 128] per-user lower-bound keys, zeroed per call (may be null)
+    float *dense;            // STORE variant: also write every score, dense[slot][item] (may be null otherwise)
+    int64_t dense_ld;        // floats per row, >= n_tiles * 32 and a multiple of 4
     unsigned long long *stamps;  // dev-only: [grid][4 waves][8] cycle sums per phase (debug bit 7), else null
     int dbg;                 // dev-only ablation switch, bits 0-2: 0 = normal, 2 = never hits, 3 = also no staging and no
                              // barrier, 4 = no staging; bit 6 (host side): extra LDS so that one workgroup fits per CU
@@ -109,7 +111,10 @@ __device__ __forceinline__ float list_tau(const float (&ls)[KL], int K)
 // grid.x = n_chunks * n_user_tiles, chunk-major so that concurrently resident workgroups
 // stream the same item chunk through L2.
 // ------------------------------------------------------------------------------------
-template <int KD, int KL, bool HAS_BASE>
+// STORE: the scores are also written out as dense rows (the same values ifr_score_dense computes), so that the
+// row-wise consumers (AUC, list metrics) cost one HBM pass instead of a second GEMM.  A user's 32 scores of a
+// tile are one 128-byte line, written as 8 x 16 bytes by the user's two half-lanes.
+template <int KD, int KL, bool HAS_BASE, bool STORE = false>
 __global__ __launch_bounds__(BLOCK, KD > 128 ? 1 : 2) void score_topk_kernel(TopkParams p)
 {
     constexpr int ROW = KD + 4;                 // padded LDS row (floats); +4 => conflict-free b128 reads
@@ -141,6 +146,8 @@ __global__ __launch_bounds__(BLOCK, KD > 128 ? 1 : 2) void score_topk_kernel(Top
         for (int g = 0; g < KD / 8; ++g) ureg[g] = *reinterpret_cast<const f32x4 *>(up + 8 * g);
     }
     const float ub = HAS_BASE ? p.ubase[uid] : 0.0f;
+    // STORE: row of this lane's user; the idle lanes of the last user tile recompute user n-1 and rewrite its values
+    float *drow = STORE ? p.dense + (live ? slot : p.n - 1) * p.dense_ld + 4 * h : nullptr;
 
     // exclusion cursor: first (tile, mask) entry with tile >= t0
     // (nt, nm) is the next entry, (nt2, nm2) the one after it: an entry is loaded at least one
@@ -276,6 +283,9 @@ __global__ __launch_bounds__(BLOCK, KD > 128 ? 1 : 2) void score_topk_kernel(Top
                 const float sc = HAS_BASE ? ((ibC[r] + ub) + accC[r]) : accC[r]; // (ibase + ubase) + dot
                 s[r] = sc;
                 hb[r] = __ballot(sc > seltau);                                  // one v_cmp into an SGPR pair
+                if (STORE && (r & 3) == 3 && t > t0)                            // items item0 + 8q .. + 3 of tile t-1
+                    *reinterpret_cast<f32x4 *>(drow + (int64_t)(t - 1) * TILE_I + 2 * (r - 3)) =
+                        f32x4{s[r - 3], s[r - 2], s[r - 1], sc};
             }
             a_cur = a_nxt;
             __builtin_amdgcn_sched_barrier(0);

@@ -245,6 +245,33 @@ class HipScorer:
             self.select_topk(ub, dense, K, out_ids[b:b + step], out_scores[b:b + step])
         return out_ids, out_scores
 
+    MAX_TOPK_WITH_DENSE = 16      # ifr_rank_topk_dense
+
+    def can_rank_topk_dense(self, K):
+        """True when rank_topk_dense serves this model and cut-off in one kernel (dot-product model, K <= 16, no
+        unknown catalogue items to pad)."""
+        return self.item_model is None and 1 <= int(K) <= self.MAX_TOPK_WITH_DENSE and \
+            max(getattr(self, "catalogue_items", 0), self.n_items) == self.n_items
+
+    def rank_topk_dense(self, user_ids, K, dense=None, out_ids=None, out_scores=None):
+        """rank_topk and score_dense in one launch (one GEMM instead of two): returns (ids [n,K], scores [n,K],
+        dense [n, n_items] view).  The dense buffer has rows of n_items rounded up to 32 floats."""
+        torch = _torch()
+        u = self._dev_i32(user_ids)
+        n = u.numel()
+        ld = (self.n_items + 31) // 32 * 32
+        if dense is None:
+            dense = torch.empty((n, ld), dtype=torch.float32, device=self.device)
+        if dense.dim() != 2 or dense.shape[0] < n or dense.shape[1] < ld or dense.stride(1) != 1 or dense.dtype != torch.float32:
+            raise ValueError(f"rank_topk_dense: dense must be float32 [>= {n}, >= {ld}] with unit column stride")
+        if out_ids is None:
+            out_ids = torch.empty((n, K), dtype=torch.int32, device=self.device)
+        if out_scores is None:
+            out_scores = torch.empty((n, K), dtype=torch.float32, device=self.device)
+        self._check(self._lib.ifr_rank_topk_dense(self._h, u.data_ptr(), n, int(K), out_ids.data_ptr(), out_scores.data_ptr(),
+                                                  dense.data_ptr(), dense.stride(0), self._stream()))
+        return out_ids, out_scores, dense[:n, : self.n_items]
+
     def select_topk(self, user_ids, scores, K, out_ids=None, out_scores=None):
         """The K <= 1024 best candidates of dense score rows in the order of rank_full (partial ranking)."""
         torch = _torch()

@@ -253,10 +253,11 @@ def _append_unknown_items(ids, users, excl, n_known, n_items):
 
 # --------------------------------------------------------------------------- ranking_eval
 def ranking_eval(model, metrics, train_set, test_set, val_set=None, rating_threshold=1.0, exclude_unknowns=True,
-                 verbose=False, *, batch_pairs=1 << 28, distributed="auto", gather_user_results=True, _engine=None):
+                 verbose=False, *, batch_pairs=None, distributed="auto", gather_user_results=True, _engine=None):
     """Evaluate `model` on ranking metrics: reference signature and return value
     (base_method.py:185-305).  Keyword-only extras: `batch_pairs` bounds users x items of a dense
-    score batch (AUC / k = -1 paths), `distributed` shards the test users over the ranks of an
+    score batch (AUC / k = -1 paths; default 2^28, and 2^32 -- a 16 GB buffer -- where the fused kernel writes
+    the rows itself), `distributed` shards the test users over the ranks of an
     initialised torch.distributed group and all-reduces the metric sums (one RCCL/gloo
     all-reduce), `gather_user_results` also gathers the per-user values to every rank."""
     if len(metrics) == 0:
@@ -316,9 +317,25 @@ def ranking_eval(model, metrics, train_set, test_set, val_set=None, rating_thres
     col_of = {}
     if n:
         dev_users = torch.as_tensor(my_users.astype(np.int32), device=eng.device)
+        # top-K cut-offs and AUC together: the fused kernel also writes the score rows AUC reads (one GEMM, not two)
+        fused_dense = bool(not need_list and ks and need_auc and hasattr(eng, "can_rank_topk_dense")
+                           and eng.can_rank_topk_dense(max(ks)))
         if not need_list and ks:
             kmax = max(ks)
-            ids, _ = eng.rank_topk(dev_users, kmax)
+            if fused_dense:
+                ld = (n_items + 31) // 32 * 32
+                step = max(1, min(n, int((batch_pairs or 1 << 32) // ld)))
+                ids = torch.empty((n, kmax), dtype=torch.int32, device=eng.device)
+                rows = torch.empty((step, ld), dtype=torch.float32, device=eng.device)
+                auc = np.empty(n)
+                for b in range(0, n, step):
+                    bu = dev_users[b:b + step]
+                    _, _, dense = eng.rank_topk_dense(bu, kmax, rows, out_ids=ids[b:b + step])
+                    auc[b:b + step] = eng.auc_dense(bu, dense).cpu().numpy()
+                del rows
+                col_of[("auc", -1)] = auc
+            else:
+                ids, _ = eng.rank_topk(dev_users, kmax)
             if n_items > eng.n_items:
                 ids = _append_unknown_items(ids, my_users, excl, eng.n_items, n_items)
             per_user, _, _ = eng.eval_topk_metrics(dev_users, ids, ks)
@@ -326,8 +343,9 @@ def ranking_eval(model, metrics, train_set, test_set, val_set=None, rating_thres
             for qi, k in enumerate(ks):
                 for ci, name in enumerate(METRIC_COLUMNS):
                     col_of[(name, k)] = per_user[:, METRICS_PER_K * qi + ci]
+        need_auc = need_auc and not fused_dense
         if need_list or need_auc:
-            step = max(1, int(batch_pairs // max(1, n_items)))
+            step = max(1, int((batch_pairs or 1 << 28) // max(1, n_items)))
             lst_ks = ks if ks else [-1]
             max_pos = int(np.diff(truth.indptr).max()) if truth.shape[0] else 0
             dense_metrics = max_pos <= MAX_DENSE_METRIC_POS

@@ -339,3 +339,25 @@ def test_save_recommendations_full_and_pooled(toy, tmp_path):
         np.testing.assert_array_equal(full[0][u][:19], pooled[0][u])
         lut = dict(zip(full[2][u].tolist(), full[1][u].tolist()))
         assert [lut[i] for i in pooled[0][u].tolist()] == pooled[1][u].tolist()
+
+
+def test_topk_metrics_with_auc_share_one_scoring_pass(toy):
+    """NDCG@10 + AUC: ranking_eval lets the fused kernel write the score rows AUC reads (ifr_rank_topk_dense).
+    Same per-user values as the separate routes (cut-off 20 keeps AUC on ifr_score_dense), also when batched."""
+    d = toy
+    train_set, test_set, val_set = _sets(d)
+    kw = dict(val_set=val_set, rating_threshold=float(d["rating_threshold"]), exclude_unknowns=True)
+    for name in ("bpr", "wmf"):
+        model = _model(d, name, train_set)
+        assert model._hip_engine().can_rank_topk_dense(10)
+        _, fused = ranking_eval(model, [M.NDCG(k=10), M.AUC(), M.Recall(k=5)], train_set, test_set, **kw)
+        _, batched = ranking_eval(_model(d, name, train_set), [M.NDCG(k=10), M.AUC(), M.Recall(k=5)], train_set, test_set,
+                                  batch_pairs=37 * 512, **kw)
+        _, apart = ranking_eval(_model(d, name, train_set), [M.NDCG(k=10), M.AUC(), M.Recall(k=5), M.NDCG(k=20)], train_set,
+                                test_set, **kw)
+        for j in range(3):
+            assert fused[j] == batched[j] == apart[j]
+        users = d[f"{name}__users"]
+        ref_auc = d[f"{name}__per_user"][:, list(d["metric_names"]).index("auc@-1")]
+        got = np.asarray([fused[1][int(u)] for u in users])
+        assert np.abs(got - ref_auc).max() < 1e-4 and abs(got.mean() - ref_auc.mean()) < 1e-6

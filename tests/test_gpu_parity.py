@@ -368,3 +368,31 @@ def test_dense_row_metrics_equal_the_ranked_list_metrics(torch):
         assert torch.equal(a_ev, b_ev) and a_ev.any() and not a_ev.all()
         np.testing.assert_allclose(b.cpu().numpy(), a.cpu().numpy(), rtol=0, atol=1e-13, equal_nan=True)
         np.testing.assert_allclose(b_sum.cpu().numpy(), a_sum.cpu().numpy(), rtol=1e-13)
+
+
+@pytest.mark.parametrize("k,bias,K,chunks", [(128, False, 10, 0), (50, True, 16, 3), (200, False, 1, 0), (96, True, 10, 5)])
+def test_topk_with_dense_rows_in_one_launch(torch, k, bias, K, chunks):
+    """ifr_rank_topk_dense = ifr_rank_topk + ifr_score_dense bit for bit (lists and rows), ragged user batch,
+    catalogue that is not a multiple of 32, any item chunking; its argument checks."""
+    from recommenders_amd import IfrError
+    w = _workload(4000 + k + K, 333, 2999, k, bias)
+    sc = _scorer(w)
+    if chunks:
+        sc.set_option("chunks", chunks)
+    users = torch.as_tensor(np.random.default_rng(K).permutation(w["n_users"])[:301].astype(np.int32), device="cuda")
+    ids0, sc0 = sc.rank_topk(users, K)
+    rows0 = sc.score_dense(users)
+    assert sc.can_rank_topk_dense(K)
+    buf = torch.full((users.numel() + 3, 3008 + 32), float("nan"), dtype=torch.float32, device="cuda")
+    ids1, sc1, rows1 = sc.rank_topk_dense(users, K, buf)
+    assert rows1.shape == rows0.shape
+    assert torch.equal(ids0, ids1) and torch.equal(sc0, sc1)
+    assert torch.equal(rows0, rows1)
+    assert torch.isnan(buf[users.numel():]).all() and torch.isnan(buf[:, 3008:]).all()      # nothing written beside the rows
+    ids2, sc2, rows2 = sc.rank_topk_dense(users[:5], K)                                       # allocates its own rows
+    assert torch.equal(ids2, ids0[:5]) and torch.equal(rows2, rows0[:5])
+    assert not sc.can_rank_topk_dense(17)
+    with pytest.raises(IfrError):
+        sc.rank_topk_dense(users, 17)
+    with pytest.raises(ValueError):
+        sc.rank_topk_dense(users, K, torch.empty((users.numel(), 2999), dtype=torch.float32, device="cuda"))
