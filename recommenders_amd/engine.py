@@ -94,6 +94,7 @@ class HipScorer:
 
     # ------------------------------------------------------------------ data
     def set_factors(self, U, V, ubase=None, ibase=None):
+        self.exclusion_source = self.truth_source = None    # the library drops CSRs of another catalogue size
         n_users, k = U.shape
         n_items, k2 = V.shape
         if k != k2:
@@ -119,6 +120,7 @@ class HipScorer:
 
     def set_item_matrix_dense(self, M, col_scale=None):
         """Item-item model with a dense M [I, I] (EASE's B, or a dense RP3-beta W); NumPy or torch."""
+        self.exclusion_source = self.truth_source = None    # the library drops CSRs of another catalogue size
         n_items = int(M.shape[0])
         if M.shape[1] != n_items:
             raise ValueError("the item matrix must be square")
@@ -177,6 +179,7 @@ class HipScorer:
 
     def set_item_matrix_csr(self, indptr, indices, values, n_items, col_scale=None):
         """Item-item model with a sparse M (CSR rows, strictly ascending columns)."""
+        self.exclusion_source = self.truth_source = None    # the library drops CSRs of another catalogue size
         pp, kp = self._any_ptr(indptr, np.int64)
         pi, ki = self._any_ptr(indices, np.int32)
         pv, kv = self._any_ptr(values, np.float32)
@@ -205,6 +208,7 @@ class HipScorer:
         return sh.value
 
     def set_exclusion_csr(self, indptr, indices):
+        self.exclusion_source = None     # ranking_eval notes here which matrix the device copy was made from
         pp, kp = self._any_ptr(indptr, np.int64)
         pi, ki = self._any_ptr(indices, np.int32)
         n_rows = len(indptr) - 1
@@ -213,6 +217,7 @@ class HipScorer:
         del kp, ki
 
     def set_truth_csr(self, indptr, indices):
+        self.truth_source = None
         pp, kp = self._any_ptr(indptr, np.int64)
         pi, ki = self._any_ptr(indices, np.int32)
         n_rows = len(indptr) - 1

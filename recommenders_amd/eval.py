@@ -299,8 +299,13 @@ def ranking_eval(model, metrics, train_set, test_set, val_set=None, rating_thres
             excl = (sp.diags(keep.astype(np.int8)) @ excl + sp.diags((~keep).astype(np.int8)) @ old).tocsr()
             excl.sort_indices()
     users = test_users[has_pos[test_users]]                      # base_method.py:258-259
-    eng.set_exclusion_csr(excl.indptr.astype(np.int64), excl.indices.astype(np.int32))
-    eng.set_truth_csr(truth.indptr.astype(np.int64), truth.indices.astype(np.int32))
+    # the memoised CSRs are uploaded once per engine: a repeated evaluation on the same splits finds them in place
+    if getattr(eng, "exclusion_source", None) is not excl:
+        eng.set_exclusion_csr(excl.indptr.astype(np.int64), excl.indices.astype(np.int32))
+        eng.exclusion_source = excl
+    if getattr(eng, "truth_source", None) is not truth:
+        eng.set_truth_csr(truth.indptr.astype(np.int64), truth.indices.astype(np.int32))
+        eng.truth_source = truth
 
     # ---- shard users over ranks
     world, rank = ifr_dist.world_and_rank(distributed)
