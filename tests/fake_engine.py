@@ -25,9 +25,13 @@ class OracleEngine:
         self.tr = (np.zeros(1, np.int64), np.zeros(0, np.int32))
 
     def set_exclusion_csr(self, indptr, indices):
+        self.exclusion_source = None              # like HipScorer: whoever uploads owns the note
+        self.uploads = getattr(self, "uploads", 0) + 1
         self.ex = (np.asarray(indptr, np.int64), np.asarray(indices, np.int32))
 
     def set_truth_csr(self, indptr, indices):
+        self.truth_source = None
+        self.uploads = getattr(self, "uploads", 0) + 1
         self.tr = (np.asarray(indptr, np.int64), np.asarray(indices, np.int32))
 
     def _row(self, csr, u):

@@ -353,6 +353,23 @@ def test_eval_csrs_are_memoised_per_split_and_notice_edits():
     assert (d[0] != ref2[0]).nnz == 0 and (d[1] != ref2[1]).nnz == 0
 
 
+def test_memoised_csrs_are_uploaded_once_per_engine(toy):
+    """A repeated ranking_eval on the same splits finds its exclusion / truth CSRs on the device; any other upload
+    (rank_batch, a metric object, another evaluation) makes the next call send them again."""
+    d = toy
+    train_set, test_set, val_set = _datasets(d)
+    eng = _engine(d, "bpr", test_set.num_users)
+    fake = types.SimpleNamespace(is_fitted=True)
+    kw = dict(rating_threshold=float(d["rating_threshold"]), _engine=eng)
+    first, _ = ifr_eval.ranking_eval(fake, [M.NDCG(k=10)], train_set, test_set, val_set, **kw)
+    assert eng.uploads == 2
+    again, _ = ifr_eval.ranking_eval(fake, [M.NDCG(k=10)], train_set, test_set, val_set, **kw)
+    assert eng.uploads == 2 and again == first
+    eng.set_exclusion_csr(np.zeros(1, np.int64), np.zeros(0, np.int32))        # somebody else's exclusions
+    third, _ = ifr_eval.ranking_eval(fake, [M.NDCG(k=10)], train_set, test_set, val_set, **kw)
+    assert eng.uploads == 4 and third == first
+
+
 def test_list_metrics_fall_back_to_sorted_lists_for_very_long_truth_rows(toy, monkeypatch):
     """Rows with more positives than ifr_eval_dense_metrics holds in LDS take ifr_rank_full + ifr_eval_ranked_metrics;
     both routes give the same values."""
