@@ -396,3 +396,24 @@ def test_topk_with_dense_rows_in_one_launch(torch, k, bias, K, chunks):
         sc.rank_topk_dense(users, 17)
     with pytest.raises(ValueError):
         sc.rank_topk_dense(users, K, torch.empty((users.numel(), 2999), dtype=torch.float32, device="cuda"))
+
+
+@pytest.mark.parametrize("K", [1, 7, 16, 20, 32])
+def test_merge_kernels_over_list_counts(torch, K):
+    """The two merge kernels (all-pairs key counting up to 256 head entries in 1 / 2 / 4 keys per lane, binary
+    searches beyond) give the oracle's lists for every number of partial lists, with ties and short rows."""
+    w = _workload(6000 + K, 200, 2500, 64, True, mean=30)
+    w["V"][40:140] = w["V"][40]                       # 100 items with identical scores per user: ties across lists
+    w["ibase"][40:140] = w["ibase"][40]
+    ptr, idx = w["excl_ptr"], w["excl_idx"]
+    keep = np.setdiff1d(np.arange(2500, dtype=np.int32), np.arange(0, 2500, 290, dtype=np.int32))   # user 0 keeps 9 items
+    w["excl_idx"] = np.concatenate([keep, idx[ptr[1]:]]).astype(np.int32)
+    w["excl_ptr"] = np.concatenate([[0], ptr[1:] - ptr[1] + len(keep)]).astype(np.int64)
+    sc = _scorer(w)
+    users = np.arange(w["n_users"], dtype=np.int32)
+    o_ids, o_sc, _, _ = _oracle(w, users, [K], K, sc.chain_order())
+    for chunks in (1, 2, 4, 5, 13, 40):               # 2 * chunks lists of K head entries each
+        sc.set_option("chunks", chunks)
+        ids, scores = sc.rank_topk(users, K)
+        np.testing.assert_array_equal(ids.cpu().numpy(), o_ids, err_msg=f"chunks={chunks}")
+        np.testing.assert_array_equal(scores.cpu().numpy(), o_sc, err_msg=f"chunks={chunks}")
