@@ -145,7 +145,7 @@ int ifr_rank_topk(ifr_handle h, const int32_t *user_ids, int64_t n, int K,
  * score vector -- ranking_eval with AUC or whole-list metrics beside NDCG@k, base_method.py:275-299, or
  * Recommender.rank, which returns the ranking AND the score vector (recommender.py:624-661) -- pays one GEMM
  * instead of two.  Dot-product models only (IFR_ERR_STATE otherwise: call ifr_rank_topk and ifr_score_dense),
- * 1 <= K <= 16, ld a multiple of 4 and >= n_items rounded up to 32 (columns n_items .. ld-1 of a row may be
+ * 1 <= K <= IFR_MAX_TOPK, ld a multiple of 4 and >= n_items rounded up to 32 (columns n_items .. ld-1 of a row may be
  * overwritten with padding scores), dense_out 16-byte aligned.  Exclusions do not alter dense_out. */
 int ifr_rank_topk_dense(ifr_handle h, const int32_t *user_ids, int64_t n, int K, int32_t *out_ids,
                         float *out_scores, float *dense_out, int64_t ld, void *stream);

@@ -133,12 +133,10 @@ template <int KD, int KL>
 void launch_topk(bool has_base, const ifr::TopkParams &p, int grid, hipStream_t s)
 {
     const size_t pad = (p.dbg & 64) ? 30000 : 0;     // dev ablation: extra LDS -> one workgroup per CU
-    if constexpr (KL == 16) {
-        if (p.dense != nullptr) {                    // also writes the dense score rows (ifr_rank_topk_dense, K <= 16)
-            if (has_base) hipLaunchKernelGGL((ifr::score_topk_kernel<KD, KL, true, true>), dim3(grid), dim3(ifr::BLOCK), pad, s, p);
-            else hipLaunchKernelGGL((ifr::score_topk_kernel<KD, KL, false, true>), dim3(grid), dim3(ifr::BLOCK), pad, s, p);
-            return;
-        }
+    if (p.dense != nullptr) {                        // also writes the dense score rows (ifr_rank_topk_dense)
+        if (has_base) hipLaunchKernelGGL((ifr::score_topk_kernel<KD, KL, true, true>), dim3(grid), dim3(ifr::BLOCK), pad, s, p);
+        else hipLaunchKernelGGL((ifr::score_topk_kernel<KD, KL, false, true>), dim3(grid), dim3(ifr::BLOCK), pad, s, p);
+        return;
     }
     if (has_base) hipLaunchKernelGGL((ifr::score_topk_kernel<KD, KL, true>), dim3(grid), dim3(ifr::BLOCK), pad, s, p);
     else hipLaunchKernelGGL((ifr::score_topk_kernel<KD, KL, false>), dim3(grid), dim3(ifr::BLOCK), pad, s, p);
@@ -710,7 +708,7 @@ static int rank_topk_item_item(ifr_handle h, const int32_t *user_ids, int64_t n,
     return IFR_OK;
 }
 
-// fused score + top-K of a dot-product model; dense != nullptr: the kernel also writes every score (K <= 16)
+// fused score + top-K of a dot-product model; dense != nullptr: the kernel also writes every score
 static int rank_topk_factor(ifr_handle h, const int32_t *user_ids, int64_t n, int K, int KL, int32_t *out_ids, float *out_scores,
                             float *dense, int64_t dense_ld, hipStream_t s);
 
@@ -736,11 +734,11 @@ int ifr_rank_topk_dense(ifr_handle h, const int32_t *user_ids, int64_t n, int K,
         return fail(h, IFR_ERR_STATE, "ifr_rank_topk_dense: needs a dot-product model (ifr_set_factors); use ifr_rank_topk + ifr_score_dense");
     if (n == 0) return IFR_OK;
     if (!user_ids || !out_ids || !out_scores || !dense_out || n < 0) return fail(h, IFR_ERR_ARG, "ifr_rank_topk_dense: null/negative argument");
-    if (K < 1 || K > 16) return fail(h, IFR_ERR_ARG, "ifr_rank_topk_dense: K must be in [1, 16]");
+    if (K < 1 || K > IFR_MAX_TOPK) return fail(h, IFR_ERR_ARG, "ifr_rank_topk_dense: K must be in [1, 32]");
     if (ld < (int64_t)h->n_tiles * ifr::TILE_I || (ld & 3) || ((uintptr_t)dense_out & 15))
         return fail(h, IFR_ERR_ARG, "ifr_rank_topk_dense: ld must be a multiple of 4 and >= n_items rounded up to 32, dense_out 16-byte aligned");
     IFR_HIP(h, hipSetDevice(h->device));
-    return rank_topk_factor(h, user_ids, n, K, 16, out_ids, out_scores, dense_out, ld, (hipStream_t)stream);
+    return rank_topk_factor(h, user_ids, n, K, K <= 16 ? 16 : 32, out_ids, out_scores, dense_out, ld, (hipStream_t)stream);
 }
 
 static int rank_topk_factor(ifr_handle h, const int32_t *user_ids, int64_t n, int K, int KL, int32_t *out_ids, float *out_scores,

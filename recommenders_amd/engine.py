@@ -250,10 +250,10 @@ class HipScorer:
             self.select_topk(ub, dense, K, out_ids[b:b + step], out_scores[b:b + step])
         return out_ids, out_scores
 
-    MAX_TOPK_WITH_DENSE = 16      # ifr_rank_topk_dense
+    MAX_TOPK_WITH_DENSE = 32      # ifr_rank_topk_dense (= IFR_MAX_TOPK)
 
     def can_rank_topk_dense(self, K):
-        """True when rank_topk_dense serves this model and cut-off in one kernel (dot-product model, K <= 16, no
+        """True when rank_topk_dense serves this model and cut-off in one kernel (dot-product model, K <= 32, no
         unknown catalogue items to pad)."""
         return self.item_model is None and 1 <= int(K) <= self.MAX_TOPK_WITH_DENSE and \
             max(getattr(self, "catalogue_items", 0), self.n_items) == self.n_items

@@ -370,7 +370,8 @@ def test_dense_row_metrics_equal_the_ranked_list_metrics(torch):
         np.testing.assert_allclose(b_sum.cpu().numpy(), a_sum.cpu().numpy(), rtol=1e-13)
 
 
-@pytest.mark.parametrize("k,bias,K,chunks", [(128, False, 10, 0), (50, True, 16, 3), (200, False, 1, 0), (96, True, 10, 5)])
+@pytest.mark.parametrize("k,bias,K,chunks", [(128, False, 10, 0), (50, True, 16, 3), (200, False, 1, 0), (96, True, 10, 5),
+                                             (128, True, 20, 0), (64, False, 32, 2)])
 def test_topk_with_dense_rows_in_one_launch(torch, k, bias, K, chunks):
     """ifr_rank_topk_dense = ifr_rank_topk + ifr_score_dense bit for bit (lists and rows), ragged user batch,
     catalogue that is not a multiple of 32, any item chunking; its argument checks."""
@@ -391,9 +392,9 @@ def test_topk_with_dense_rows_in_one_launch(torch, k, bias, K, chunks):
     assert torch.isnan(buf[users.numel():]).all() and torch.isnan(buf[:, 3008:]).all()      # nothing written beside the rows
     ids2, sc2, rows2 = sc.rank_topk_dense(users[:5], K)                                       # allocates its own rows
     assert torch.equal(ids2, ids0[:5]) and torch.equal(rows2, rows0[:5])
-    assert not sc.can_rank_topk_dense(17)
+    assert not sc.can_rank_topk_dense(33)
     with pytest.raises(IfrError):
-        sc.rank_topk_dense(users, 17)
+        sc.rank_topk_dense(users, 33)
     with pytest.raises(ValueError):
         sc.rank_topk_dense(users, K, torch.empty((users.numel(), 2999), dtype=torch.float32, device="cuda"))
 
