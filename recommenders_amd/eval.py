@@ -160,6 +160,17 @@ def cache_rankings(model, user_idx, item_indices, k=-1):
     return item_rank, item_scores
 
 
+def _rows_that_fit(eng, want_rows, row_floats):
+    """Dense score rows per batch: what the caller's bound asks for, at most half of the free device memory."""
+    dev = getattr(eng, "device", None)
+    if dev is None or getattr(dev, "type", "cpu") != "cuda":
+        return max(1, int(want_rows))
+    import torch
+    free, _ = torch.cuda.mem_get_info(dev)
+    reusable = torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)     # cached blocks torch can hand out again
+    return max(1, min(int(want_rows), int((free + reusable) // 2) // (4 * int(row_floats))))
+
+
 def export_candidate_pools(model, pool_size, batch_users=1 << 16, _engine=None):
     """Heads of the cached rankings for the re-ranking stage: the re-rankers keep only the first `pool_size`
     ranked items of a user (rerankers/reranker.py:620-639) and look their scores up through
@@ -329,7 +340,7 @@ def ranking_eval(model, metrics, train_set, test_set, val_set=None, rating_thres
             kmax = max(ks)
             if fused_dense:
                 ld = (n_items + 31) // 32 * 32
-                step = max(1, min(n, int((batch_pairs or 1 << 32) // ld)))
+                step = _rows_that_fit(eng, min(n, int((batch_pairs or 1 << 32) // ld)), ld)
                 ids = torch.empty((n, kmax), dtype=torch.int32, device=eng.device)
                 rows = torch.empty((step, ld), dtype=torch.float32, device=eng.device)
                 auc = np.empty(n)
@@ -356,7 +367,7 @@ def ranking_eval(model, metrics, train_set, test_set, val_set=None, rating_thres
             # rows only (counting metrics, AUC): 16 GB batches, large launches run 20 % faster per user than 1 GB
             # ones; the sorted-list fallback also holds 64-bit sort keys and ids per pair, so it keeps 2^28 pairs
             default_pairs = 1 << 32 if (dense_metrics or not need_list) else 1 << 28
-            step = max(1, int((batch_pairs or default_pairs) // max(1, n_items)))
+            step = _rows_that_fit(eng, (batch_pairs or default_pairs) // max(1, n_items), n_items)
             per_list = np.empty((n, METRICS_PER_K * len(lst_ks) + 2)) if need_list else None
             auc = np.empty(n) if need_auc else None
             for b in range(0, n, step):
