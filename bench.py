@@ -4,12 +4,21 @@ Contract (see the task statement): `python bench.py --gpus N --steps K --warmup 
 N > 1 the driver launches it under torch.distributed.run, one rank per GPU.  Rank 0 prints
 ONE JSON line.
 
-Workload at N = 1 (and per rank for N > 1, weak scaling): BASELINE.json configs[1],
+Headline workload at N = 1 (and per rank for N > 1, weak scaling): BASELINE.json configs[1],
 "WMF k=128 on MovieLens-20M shape" = 138,493 users x 26,744 items, ~20 M interactions,
 synthetic (recommenders_amd/synth.py).  One step = one pass of the hot path over all of the
 rank's users: fused score + exclusion + top-10 (ifr_rank_topk), NDCG@10 / Recall@10 /
 Precision@10 (ifr_eval_topk_metrics), the all-reduce of the metric sums (N > 1) and the
 D2H copy of the top-10 lists.  Model and CSR data are resident in HBM before timing starts.
+
+The same JSON line carries `extra_configs`: the other BASELINE.json configurations, timed in
+this process after the headline with their own step counts, each with its own `roofline`,
+and at N = 1 `cpu_baseline` + `parity_on_cpu_sample`:
+  c3_mf_shard    configs[2] as one GPU sees it: 1,250,000 users (10 M / 8) x 1,000,000 items, k = 128, biases;
+                 at N ranks every rank ranks its own 1.25 M-user shard, so N = 8 is the 10 M x 1 M job
+  c4_ease_mind   configs[3]: EASE-style dense B 50 K x 50 K                      (N = 1 only)
+  c5_rp3_ebnerd  configs[4]: RP3-beta-style CSR W, 125 K items x 256 neighbours   (N = 1 only)
+`--config X` makes X the headline instead (no extras); `--no-extra` drops them.
 """
 import argparse
 import json
@@ -26,12 +35,45 @@ PEAK_F32_MFMA_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md, "Peak
 PEAK_HBM_GBS = 8000.0            # same guide: HBM3E ~8 TB/s
 TOPK = 10
 
+# rocprofv3 --pmc passes of `python bench.py --config X` committed under profiles/ (tools/prof.sh): HBM bytes per launch
+# of the dominant kernel.  A constant from that file, not a measurement of the run that prints it: `traffic_source`.
+PROFILED = {"c2_wmf_ml20m": ("r01_c2_pmc.json", 138493, 26744), "c4_ease_mind": ("r01_c4_pmc.json", 262144, 50000),
+            "c5_rp3_ebnerd": ("r01_c5_pmc.json", 1048576, 125000), "c3_mf_shard": ("r02_c3_pmc.json", 1250000, 1000000)}
+for _cfg in list(PROFILED):           # a newer round's profile of the same command wins
+    _r2 = PROFILED[_cfg][0].replace("r01_", "r02_")
+    if os.path.exists(os.path.join(ROOT, "profiles", _r2)):
+        PROFILED[_cfg] = (_r2,) + PROFILED[_cfg][1:]
+
+
+def host_threads():
+    """Threads for the CPU baseline: the CPU share this process was given (scheduler affinity, capped by the
+    OMP_NUM_THREADS the box exports for one GPU's share), not the machine's core count."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    env = os.environ.get("OMP_NUM_THREADS", "")
+    if env.isdigit() and int(env) > 0:
+        n = min(n, int(env))
+    return max(1, n)
+
+
+def host_description(threads):
+    model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return {"cores": threads, "host_cpus": os.cpu_count(), "cpu_model": model,
+            "threads_source": "scheduler affinity capped by OMP_NUM_THREADS (the box's CPU share for one GPU)"}
+
 
 def cpu_baseline(w, n_sample, chain):
     """The oracle's C port of the per-user reference loop (oracle/ifr_oracle.c), timed on this
     box's host cores over a bounded user sample of the same workload."""
     from oracle import oracle as orc
-    threads = min(16, os.cpu_count() or 1)
+    threads = host_threads()
     users = np.arange(n_sample, dtype=np.int32)
     kp = chain[chain < w["k"]]
     t = time.perf_counter()
@@ -39,15 +81,17 @@ def cpu_baseline(w, n_sample, chain):
         w["U"], w["V"], w["ibase"], w["ubase"], users, w["excl_ptr"], w["excl_idx"], w["truth_ptr"], w["truth_idx"],
         [TOPK], False, TOPK, kperm=kp, n_threads=threads)
     dt = time.perf_counter() - t
-    return dict(value=n_sample / dt, unit="users/s", cores=threads, kind="port",
-                sample=f"{n_sample} users x {w['n_items']} items of the same workload, "
-                       f"oracle/ifr_oracle.c orc_ranking_eval_factor, {dt:.1f} s"), ids, met, ev
+    out = dict(value=n_sample / dt, unit="users/s", kind="port",
+               sample=f"{n_sample} users x {w['n_items']} items of the same workload, "
+                      f"oracle/ifr_oracle.c orc_ranking_eval_factor, {dt:.1f} s")
+    out.update(host_description(threads))
+    return out, ids, met, ev
 
 
 def cpu_baseline_item(w, n_sample, shift):
     """The same per-user loop for an item-item model (oracle/ifr_oracle.c orc_ranking_eval_item)."""
     from oracle import oracle as orc
-    threads = min(16, os.cpu_count() or 1)
+    threads = host_threads()
     users = np.arange(n_sample, dtype=np.int32)
     M = w["M"]
     if M is not None and not isinstance(M, np.ndarray):
@@ -58,9 +102,11 @@ def cpu_baseline_item(w, n_sample, shift):
                                                w["h_val"], users, w["excl_ptr"], w["excl_idx"], w["truth_ptr"],
                                                w["truth_idx"], [TOPK], False, TOPK, n_threads=threads)
     dt = time.perf_counter() - t
-    return dict(value=n_sample / dt, unit="users/s", cores=threads, kind="port",
-                sample=f"{n_sample} users x {w['n_items']} items of the same workload, "
-                       f"oracle/ifr_oracle.c orc_ranking_eval_item, {dt:.1f} s"), ids, met, ev
+    out = dict(value=n_sample / dt, unit="users/s", kind="port",
+               sample=f"{n_sample} users x {w['n_items']} items of the same workload, "
+                      f"oracle/ifr_oracle.c orc_ranking_eval_item, {dt:.1f} s")
+    out.update(host_description(threads))
+    return out, ids, met, ev
 
 
 def item_algorithmic_bytes(w):
@@ -89,73 +135,87 @@ def cpu_strong(w, n_sample):
     return dict(value=done / dt, unit="users/s", kind="numpy sgemm+argpartition", sample=f"{done} users, {dt:.1f} s")
 
 
-PROFILED = {"c2_wmf_ml20m": ("r01_c2_pmc.json", 138493, 26744), "c4_ease_mind": ("r01_c4_pmc.json", 262144, 50000),
-            "c5_rp3_ebnerd": ("r01_c5_pmc.json", 1048576, 125000)}
-
-
 def measured_traffic(config, n_users, n_items):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same
-    command (profiles/*_pmc.json, made by tools/prof.sh); None when the workload differs."""
+    """(HBM bytes per launch of the dominant kernel, source file) from the committed rocprofv3 PMC passes of this same
+    command; (None, None) when the workload differs from the profiled one."""
     if config not in PROFILED:
-        return None
+        return None, None
     name, nu, ni = PROFILED[config]
     path = os.path.join(ROOT, "profiles", name)
     if (n_users, n_items) != (nu, ni) or not os.path.exists(path):
-        return None
+        return None, None
     with open(path) as f:
-        return json.load(f)["hbm_traffic_per_launch_bytes"]["total_corrected"]
+        return json.load(f)["hbm_traffic_per_launch_bytes"]["total_corrected"], "profiles/" + name
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", default="c2_wmf_ml20m")
-    ap.add_argument("--users", type=int, default=None, help="override users per rank (debug only)")
-    ap.add_argument("--items", type=int, default=None, help="override catalogue size (debug only)")
-    ap.add_argument("--cpu-sample", type=int, default=None, help="users in the CPU baseline sample")
-    ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--auc", action="store_true", help="second variant of SURVEY.md 8d: also AUC (dense score rows + ifr_auc_dense)")
-    args = ap.parse_args()
+class Dist:
+    """The N > 1 plumbing: RCCL ("nccl") all-reduce on the device, or through host memory in a gloo rehearsal."""
 
-    import torch
-    import torch.distributed as dist
+    def __init__(self, world, dev):
+        self.world, self.dev = world, dev
+
+    def all_reduce(self, t, op=None):
+        import torch.distributed as dist
+        op = dist.ReduceOp.SUM if op is None else op
+        if dist.get_backend() == "nccl":
+            dist.all_reduce(t, op=op)
+            return t
+        c = t.cpu()
+        dist.all_reduce(c, op=op)
+        return c.to(t.device)
+
+    def fence(self):
+        import torch
+        torch.cuda.synchronize(self.dev)
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+            torch.cuda.synchronize(self.dev)
+
+
+def build_workload(config, args, rank, dev):
+    """(engine with model + CSRs resident, workload dict with the HOST arrays the CPU baseline samples)."""
     from recommenders_amd import HipScorer, synth
-    if args.cpu_sample is None:
-        args.cpu_sample = 65536 if args.config == "c2_wmf_ml20m" else (4096 if args.config == "c3_mf_shard" else 16384)
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    # one rank per GPU; a rehearsal with more ranks than GPUs (IFR_BENCH_BACKEND=gloo on a one-GPU box) shares devices
-    local = local % max(1, torch.cuda.device_count())
-    dev = torch.device("cuda", local)
-    torch.cuda.set_device(dev)
-    if world > 1:
-        backend = os.environ.get("IFR_BENCH_BACKEND", "nccl")       # "nccl" is RCCL on ROCm
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group(backend)
-
-    # each rank owns one user shard of the configured size (weak scaling); item-side parameters replicated
-    item_model = args.config in synth.ITEM_CONFIGS
-    sc = HipScorer(local)
-    if item_model:
-        w = synth.make_item(args.config, n_users=args.users, n_items=args.items,
-                            seed=synth.ITEM_CONFIGS[args.config][3] + 1000 * rank, device=dev)
+    sc = HipScorer(dev.index)
+    dbg = int(os.environ.get("IFR_DEBUG_MODE", "0"))          # dev-only kernel ablations (tools/): set here, not in the library
+    if dbg:
+        sc.set_option("debug_mode", dbg)
+    if os.environ.get("IFR_CHUNKS"):
+        sc.set_option("chunks", int(os.environ["IFR_CHUNKS"]))
+    if config in synth.ITEM_CONFIGS:
+        w = synth.make_item(config, n_users=args.users, n_items=args.items,
+                            seed=synth.ITEM_CONFIGS[config][3] + 1000 * rank, device=dev)
         if w["M"] is not None:
             sc.set_item_matrix_dense(w["M"], w["col_scale"])
         else:
             sc.set_item_matrix_csr(w["m_ptr"], w["m_idx"], w["m_val"], w["n_items"], w["col_scale"])
         sc.set_history_csr(w["h_ptr"], w["h_idx"], w["h_val"])
+        sc.set_exclusion_csr(w["excl_ptr"], w["excl_idx"])
+        sc.set_truth_csr(w["truth_ptr"], w["truth_idx"])
+    elif config == "c3_mf_shard" and not args.host_synth:
+        # 1.25 M users x 60 interactions: generated on the device (seconds instead of minutes of NumPy); the CPU
+        # baseline gets host copies of V and of the sampled users' rows only
+        dw = synth.make_c3_device(n_users=args.users, n_items=args.items, seed=synth.CONFIGS[config][4] + 1000 * rank,
+                                  device=dev)
+        sc.set_factors(dw["U"], dw["V"], dw["ubase"], dw["ibase"])
+        sc.set_exclusion_csr(dw["excl_ptr"], dw["excl_idx"])
+        sc.set_truth_csr(dw["truth_ptr"], dw["truth_idx"])
+        m = min(args.cpu_sample_of(config), dw["n_users"])
+        w = synth.host_sample(dw, m)
+        del dw
     else:
-        w = synth.make(args.config, n_users=args.users, n_items=args.items,
-                       seed=synth.CONFIGS[args.config][4] + 1000 * rank)
+        w = synth.make(config, n_users=args.users, n_items=args.items, seed=synth.CONFIGS[config][4] + 1000 * rank)
         sc.set_factors(w["U"], w["V"], w["ubase"], w["ibase"])
-    sc.set_exclusion_csr(w["excl_ptr"], w["excl_idx"])
-    sc.set_truth_csr(w["truth_ptr"], w["truth_idx"])
+        sc.set_exclusion_csr(w["excl_ptr"], w["excl_idx"])
+        sc.set_truth_csr(w["truth_ptr"], w["truth_idx"])
+    return sc, w
+
+
+def run_config(config, args, steps, warmup, world, rank, dev, D, with_cpu, auc=False):
+    """Time `steps` passes of the hot path over this rank's users of `config`; rank 0 returns the result fields."""
+    import torch
+    sc, w = build_workload(config, args, rank, dev)
+    item_model = w.get("M", None) is not None or w.get("m_ptr", None) is not None
     n = w["n_users"]
     users = torch.arange(n, dtype=torch.int32, device=dev)
     # two sets of output buffers: the D2H copy of step i's top-10 lists runs on its own stream while step i + 1
@@ -171,11 +231,11 @@ def main():
 
     # AUC variant: dot-product models let the fused kernel write the score rows the AUC kernel reads
     # (ifr_rank_topk_dense, up to a 16 GB buffer per batch of users); item-item models score the rows separately
-    auc_fused = bool(args.auc and sc.can_rank_topk_dense(TOPK))
+    auc_fused = bool(auc and sc.can_rank_topk_dense(TOPK))
     auc_ld = (w["n_items"] + 31) // 32 * 32
-    auc_rows = max(1, min(n, ((1 << 32) if auc_fused else (1 << 28)) // auc_ld)) if args.auc else 0
-    auc_buf = torch.empty((auc_rows, auc_ld), dtype=torch.float32, device=dev) if args.auc else None
-    auc_out = torch.empty((n,), dtype=torch.float64, device=dev) if args.auc else None
+    auc_rows = max(1, min(n, ((1 << 32) if auc_fused else (1 << 28)) // auc_ld)) if auc else 0
+    auc_buf = torch.empty((auc_rows, auc_ld), dtype=torch.float32, device=dev) if auc else None
+    auc_out = torch.empty((n,), dtype=torch.float64, device=dev) if auc else None
 
     def step():
         buf = step_no[0] & 1
@@ -190,13 +250,13 @@ def main():
         else:
             sc.rank_topk(users, TOPK, ids, scores)
         per_user, evaluated, sums = sc.eval_topk_metrics(users, ids, [TOPK])
-        if args.auc and not auc_fused:
+        if auc and not auc_fused:
             for b in range(0, n, auc_rows):
                 ub = users[b:b + auc_rows]
                 dense = sc.score_dense(ub, auc_buf[: ub.numel(), : w["n_items"]])
                 auc_out[b:b + auc_rows] = sc.auc_dense(ub, dense)
         if world > 1:
-            sums = all_reduce(sums)                    # RCCL: per-metric sums + evaluated-user count
+            sums = D.all_reduce(sums)                  # RCCL: per-metric sums + evaluated-user count
         ready[buf].record()
         copy_stream.wait_event(ready[buf])
         with torch.cuda.stream(copy_stream):
@@ -205,98 +265,149 @@ def main():
             copied[buf].record()
         return sums
 
-    def all_reduce(t, op=None):
-        """In place on the device with RCCL; through host memory in a gloo rehearsal."""
-        op = dist.ReduceOp.SUM if op is None else op
-        if dist.get_backend() == "nccl":
-            dist.all_reduce(t, op=op)
-            return t
-        c = t.cpu()
-        dist.all_reduce(c, op=op)
-        return c.to(t.device)
-
-    def fence():
-        torch.cuda.synchronize(dev)
-        if world > 1:
-            dist.barrier()
-            torch.cuda.synchronize(dev)
-
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step()
-    fence()
+    D.fence()
     sc.profile_enable(True)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         sums = step()
-    fence()
+    D.fence()
     dt = time.perf_counter() - t0
     sc.profile_enable(False)
     kern_ms, launches, pairs = sc.profile_read()
     if world > 1:
-        tmax = all_reduce(torch.tensor([dt], dtype=torch.float64, device=dev), dist.ReduceOp.MAX)
+        import torch.distributed as dist
+        tmax = D.all_reduce(torch.tensor([dt], dtype=torch.float64, device=dev), dist.ReduceOp.MAX)
         dt = float(tmax.item())
+    if rank != 0:
+        sc.close()
+        return None
 
-    if rank == 0:
-        sums = sums.cpu().numpy()
-        avg_ms = kern_ms / max(launches, 1)
+    sums = sums.cpu().numpy()
+    avg_ms = kern_ms / max(launches, 1)
+    traffic, traffic_source = measured_traffic(config, n, w["n_items"])
+    if item_model:
+        bytes_per_launch = item_algorithmic_bytes(w)
+        achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
+        dense = w["M"] is not None
+        kind = "EASE-style dense item-item B" if dense else "RP3-beta-style sparse item-item W"
+        workload = (f"{config}: {kind}, {n} users/GPU x {w['n_items']} items, "
+                    f"{float(w['h_ptr'][n]) / n:.1f} history items/user"
+                    + ("" if dense else f", {int(np.diff(w['m_ptr']).mean())} neighbours/row")
+                    + f", top-{TOPK} + NDCG@{TOPK}/Recall@{TOPK}/Precision@{TOPK}")
+        roof = {"bound": "hbm", "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                "frac": achieved / PEAK_HBM_GBS, "traffic": traffic, "traffic_source": traffic_source,
+                "kernel": "item_item_kernel" if dense else "item_sparse_topk_kernel", "avg_launch_ms": avg_ms, "launches": launches,
+                "bytes_per_launch": bytes_per_launch}
+        cfg = {"workload": workload, "users_per_gpu": n, "items": w["n_items"], "topk": TOPK,
+               "parallelism": f"users sharded x{world}, item matrix replicated"}
+    else:
+        flops_per_launch = 2.0 * n * w["n_items"] * w["k"]       # 2*I*k per user x users per launch
+        achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12
+        roof = {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic, "traffic_source": traffic_source,
+                "kernel": "score_topk_kernel", "avg_launch_ms": avg_ms, "launches": launches,
+                "flops_per_launch": flops_per_launch}
+        cfg = {"workload": f"{config}: dot-product model, {n} users/GPU x {w['n_items']} items, "
+                           f"k={w['k']}, top-{TOPK} + NDCG@{TOPK}/Recall@{TOPK}/Precision@{TOPK}",
+               "users_per_gpu": n, "items": w["n_items"], "k": w["k"], "topk": TOPK,
+               "parallelism": f"users sharded x{world}, item factors replicated"}
+    out = {
+        "value": world * n * steps / dt,
+        "unit": "users/s",
+        "n_gpus": world,
+        "steps": steps,
+        "warmup": warmup,
+        "ms_per_step": 1e3 * dt / steps,
+        "scaling": "weak",
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": cfg,
+        "roofline": roof,
+        "variant": "top-10 + NDCG/Recall/Precision@10" + ((" + AUC (score rows written by the fused kernel)" if auc_fused else " + AUC (dense rows)") if auc else ""),
+        "eval": {"ndcg@10": sums[0] / sums[-1], "recall@10": sums[1] / sums[-1],
+                 "precision@10": sums[2] / sums[-1], "n_evaluated": float(sums[-1])},
+    }
+    if auc:
+        out["eval"]["auc"] = float(torch.nanmean(auc_out).item())
+    if with_cpu:
+        m = min(args.cpu_sample_of(config), n, w.get("host_rows", n))
         if item_model:
-            bytes_per_launch = item_algorithmic_bytes(w)
-            achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
-            dense = w["M"] is not None
-            kind = "EASE-style dense item-item B" if dense else "RP3-beta-style sparse item-item W"
-            workload = (f"{args.config}: {kind}, {n} users/GPU x {w['n_items']} items, "
-                        f"{float(w['h_ptr'][n]) / n:.1f} history items/user"
-                        + ("" if dense else f", {int(np.diff(w['m_ptr']).mean())} neighbours/row")
-                        + f", top-{TOPK} + NDCG@{TOPK}/Recall@{TOPK}/Precision@{TOPK}")
-            roof = {"bound": "hbm", "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                    "frac": achieved / PEAK_HBM_GBS, "traffic": measured_traffic(args.config, n, w["n_items"]),
-                    "kernel": "item_item_kernel" if dense else "item_sparse_topk_kernel", "avg_launch_ms": avg_ms, "launches": launches,
-                    "bytes_per_launch": bytes_per_launch}
-            cfg = {"workload": workload, "users_per_gpu": n, "items": w["n_items"], "topk": TOPK,
-                   "parallelism": f"users sharded x{world}, item matrix replicated"}
+            shift = sc.item_fixed_point_shift() if w["M"] is None else 0
+            base, o_ids, _, _ = cpu_baseline_item(w, m, shift)
         else:
-            flops_per_launch = 2.0 * n * w["n_items"] * w["k"]       # 2*I*k per user (SURVEY 8d) x users per launch
-            achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12
-            roof = {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": achieved / PEAK_F32_MFMA_TFLOPS,
-                    "traffic": measured_traffic(args.config, n, w["n_items"]),
-                    "kernel": "score_topk_kernel", "avg_launch_ms": avg_ms, "launches": launches,
-                    "flops_per_launch": flops_per_launch}
-            cfg = {"workload": f"{args.config}: dot-product model, {n} users/GPU x {w['n_items']} items, "
-                               f"k={w['k']}, top-{TOPK} + NDCG@{TOPK}/Recall@{TOPK}/Precision@{TOPK}",
-                   "users_per_gpu": n, "items": w["n_items"], "k": w["k"], "topk": TOPK,
-                   "parallelism": f"users sharded x{world}, item factors replicated"}
-        out = {
-            "metric": "users ranked/sec (full-catalogue top-10 + NDCG/Recall)",
-            "value": world * n * args.steps / dt,
-            "unit": "users/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": 1e3 * dt / args.steps,
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "f32",
-            "data": "synthetic",
-            "config": cfg,
-            "roofline": roof,
-            "variant": "top-10 + NDCG/Recall/Precision@10" + ((" + AUC (score rows written by the fused kernel)" if auc_fused else " + AUC (dense rows)") if args.auc else ""),
-            "eval": {"ndcg@10": sums[0] / sums[-1], "recall@10": sums[1] / sums[-1],
-                     "precision@10": sums[2] / sums[-1], "n_evaluated": float(sums[-1])},
-        }
-        if args.auc:
-            out["eval"]["auc"] = float(torch.nanmean(auc_out).item())
-        if world == 1 and not args.no_cpu:
-            m = min(args.cpu_sample, n)
-            if item_model:
-                shift = sc.item_fixed_point_shift() if w["M"] is None else 0
-                base, o_ids, _, _ = cpu_baseline_item(w, m, shift)
-            else:
-                base, o_ids, _, _ = cpu_baseline(w, m, sc.chain_order())
+            base, o_ids, _, _ = cpu_baseline(w, m, sc.chain_order())
+            if config == "c2_wmf_ml20m":
                 out["cpu_baseline_strong"] = cpu_strong(w, min(2048, n))
-            out["cpu_baseline"] = base
-            out["parity_on_cpu_sample"] = {"users": m, "top10_ids_equal": bool((h_ids2[(step_no[0] - 1) & 1][:m].numpy() == o_ids).all())}
+        out["cpu_baseline"] = base
+        out["parity_on_cpu_sample"] = {"users": m, "top10_ids_equal": bool((h_ids2[(step_no[0] - 1) & 1][:m].numpy() == o_ids).all())}
+    sc.close()
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default=None, help="headline configuration (default c2_wmf_ml20m with the others as extra_configs)")
+    ap.add_argument("--users", type=int, default=None, help="override users per rank (debug only)")
+    ap.add_argument("--items", type=int, default=None, help="override catalogue size (debug only)")
+    ap.add_argument("--cpu-sample", type=int, default=None, help="users in the CPU baseline sample")
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="headline only")
+    ap.add_argument("--host-synth", action="store_true", help="c3_mf_shard: NumPy generator (Zipf items) instead of the device one")
+    ap.add_argument("--auc", action="store_true", help="second variant of SURVEY.md 8d: also AUC (dense score rows + ifr_auc_dense)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    def cpu_sample_of(config):
+        if args.cpu_sample is not None:
+            return args.cpu_sample
+        return {"c2_wmf_ml20m": 65536, "c3_mf_shard": 2048}.get(config, 16384)
+    args.cpu_sample_of = cpu_sample_of
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    # one rank per GPU; a rehearsal with more ranks than GPUs (IFR_BENCH_BACKEND=gloo on a one-GPU box) shares devices
+    local = local % max(1, torch.cuda.device_count())
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    if world > 1:
+        backend = os.environ.get("IFR_BENCH_BACKEND", "nccl")       # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
+    D = Dist(world, dev)
+
+    headline = args.config or "c2_wmf_ml20m"
+    with_cpu = world == 1 and not args.no_cpu
+    res = run_config(headline, args, args.steps, args.warmup, world, rank, dev, D, with_cpu, auc=args.auc)
+    extras = []
+    if args.config is None and not args.no_extra and args.users is None and args.items is None:
+        # (config, steps, warm-up): bounded so that the whole default run stays within a few minutes
+        plan = [("c3_mf_shard", 2, 1)] + ([("c4_ease_mind", 3, 1), ("c5_rp3_ebnerd", 3, 1)] if world == 1 else [])
+        for cfg_name, k_steps, k_warm in plan:
+            torch.cuda.empty_cache()
+            r = run_config(cfg_name, args, k_steps, k_warm, world, rank, dev, D, with_cpu)
+            if r is not None:
+                r["name"] = cfg_name
+                extras.append(r)
+    if rank == 0:
+        out = {"metric": "users ranked/sec (full-catalogue top-10 + NDCG/Recall)"}
+        out.update(res)
+        out["higher_is_better"] = True
+        out["vs_baseline"] = None
+        if extras:
+            out["extra_configs"] = extras
+        order = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                 "vs_baseline", "dtype", "data", "config", "roofline"]
+        out = {**{k: out[k] for k in order}, **{k: v for k, v in out.items() if k not in order}}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -49,7 +49,9 @@ const char *ifr_last_error(ifr_handle h);
 
 /* Launch tuning (no reference counterpart).  "chunks": item chunks per user tile in the fused
  * kernel (0 = heuristic); "target_blocks": workgroups the heuristic aims for; "catalogue_items":
- * see ifr_pad_scores_min. */
+ * see ifr_pad_scores_min; "share_bounds": 0 switches the per-user bound words between item chunks off;
+ * "debug_mode" / "csr_pass_entries": development ablations (results may change).  Options are per handle and
+ * set only through this call: the library reads no environment variable. */
 int ifr_set_option(ifr_handle h, const char *name, int64_t value);
 
 /* Model parameters of a dot-product model: score(u,i) = (ibase[i] + ubase[u]) + <U[u], V[i]>.
@@ -150,6 +152,21 @@ int ifr_rank_topk(ifr_handle h, const int32_t *user_ids, int64_t n, int K,
 int ifr_rank_topk_dense(ifr_handle h, const int32_t *user_ids, int64_t n, int K, int32_t *out_ids,
                         float *out_scores, float *dense_out, int64_t ld, void *stream);
 
+/* ifr_rank_topk for callers that cannot allocate: code under HIP graph capture, tight serving loops, harnesses that
+ * forbid hipMalloc.  (No counterpart in the reference.)  Same arguments, same results bit for bit as ifr_rank_topk for
+ * a dot-product model (IFR_ERR_STATE otherwise), but the call makes no hipMalloc / hipFree / allocating library call:
+ * the partial top-K lists and per-user bound words live in a static __device__ array of IFR_NOALLOC_SCRATCH_BYTES that
+ * every GPU the library runs on holds until the process ends (its per-device address is looked up once in ifr_create).
+ * Limits: n <= IFR_NOALLOC_MAX_USERS users per call (IFR_ERR_ARG beyond; with K > 16 the lists are twice as wide and
+ * the static workspace holds fewer item chunks, never fewer users); K <= IFR_MAX_TOPK; no profiling events are
+ * recorded for it.  All calls on one GPU share that GPU's array -- whatever handle they use -- and the array keeps the
+ * last call's contents (the call clears what it needs at zero itself): calls that overlap on one GPU, on different
+ * streams or from different handles, race.  Calls on one stream are ordered by it. */
+#define IFR_NOALLOC_SCRATCH_BYTES (64u << 20)
+#define IFR_NOALLOC_MAX_USERS 65536
+int ifr_rank_topk_noalloc(ifr_handle h, const int32_t *user_ids, int64_t n, int K,
+                          int32_t *out_ids, float *out_scores, void *stream);
+
 #define IFR_METRICS_PER_K 6  /* per cut-off: ndcg, recall, precision, hit ratio, f1, ncrr */
 
 /* Ranking metrics from top-K lists against the truth CSR.  Replaces NDCG.compute, Recall.compute,
@@ -233,6 +250,11 @@ int ifr_pad_scores_min(ifr_handle h, float *scores, int64_t n, int64_t ld, void 
  * since the last read. */
 int ifr_profile_enable(ifr_handle h, int on);
 int ifr_profile_read(ifr_handle h, double *kernel_ms, int64_t *launches, double *pairs_scored);
+
+/* Development only (no reference counterpart): per-phase cycle sums of the fused kernel's main loop, written when the
+ * library is built with `make STAMPS=1` and the option "debug_mode" has bit 7 set (tools/stamps.py).  out: host
+ * [cap] 64-bit words, *n = words written ([grid][4 waves][8]); 0 words in a normal build. */
+int ifr_debug_read_stamps(ifr_handle h, unsigned long long *out, int64_t cap, int64_t *n);
 
 /* The k-index order of the fp32 fma chain the kernels accumulate each dot product in
  * (perm[t] = factor index consumed at chain step t, for the padded dimension the handle

@@ -37,6 +37,7 @@ SIGNATURES = {
     "ifr_set_exclusion_csr": (ctypes.c_int, [vp, vp, vp, ctypes.c_int64, ctypes.c_int64]),
     "ifr_set_truth_csr": (ctypes.c_int, [vp, vp, vp, ctypes.c_int64, ctypes.c_int64]),
     "ifr_rank_topk": (ctypes.c_int, [vp, vp, ctypes.c_int64, ctypes.c_int, vp, vp, vp]),
+    "ifr_rank_topk_noalloc": (ctypes.c_int, [vp, vp, ctypes.c_int64, ctypes.c_int, vp, vp, vp]),
     "ifr_rank_topk_dense": (ctypes.c_int, [vp, vp, ctypes.c_int64, ctypes.c_int, vp, vp, vp, ctypes.c_int64, vp]),
     "ifr_eval_topk_metrics": (ctypes.c_int, [vp, vp, ctypes.c_int64, vp, ctypes.c_int, c_i32p, ctypes.c_int,
                                              vp, vp, vp, vp]),
@@ -49,6 +50,7 @@ SIGNATURES = {
     "ifr_pad_scores_min": (ctypes.c_int, [vp, vp, ctypes.c_int64, ctypes.c_int64, vp]),
     "ifr_profile_enable": (ctypes.c_int, [vp, ctypes.c_int]),
     "ifr_profile_read": (ctypes.c_int, [vp, c_f64p, c_i64p, c_f64p]),
+    "ifr_debug_read_stamps": (ctypes.c_int, [vp, vp, ctypes.c_int64, c_i64p]),
     "ifr_factor_chain_order": (ctypes.c_int, [vp, c_i32p, ctypes.POINTER(ctypes.c_int)]),
 }
 

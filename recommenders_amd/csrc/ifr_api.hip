@@ -34,6 +34,25 @@ int launch_rank_full(const float *scores, int64_t ld, const int32_t *user_ids, i
 
 enum { MODE_NONE = 0, MODE_FACTOR = 1, MODE_ITEM_DENSE = 2, MODE_ITEM_CSR = 3 };
 
+// Workspace of ifr_rank_topk_noalloc (include/ifr.h): partial top-K lists + per-user bound words of one call.
+// Every GPU the library runs on holds its own copy until the process ends; host code never uses the array's
+// name as an address, only the per-device pointer hipGetSymbolAddress returned (scratch_of_device).
+static __device__ __align__(256) unsigned char scratch[IFR_NOALLOC_SCRATCH_BYTES];
+enum { MAX_DEVICES = 64 };
+static void *g_scratch_ptr[MAX_DEVICES];
+
+// address of `scratch` on the CURRENT device (must be `device`), looked up once per device
+static void *scratch_of_device(int device)
+{
+    if (device < 0 || device >= MAX_DEVICES) return nullptr;
+    if (!g_scratch_ptr[device]) {
+        void *p = nullptr;
+        if (hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)) != hipSuccess) return nullptr;
+        g_scratch_ptr[device] = p;
+    }
+    return g_scratch_ptr[device];
+}
+
 struct ifr_handle_s {
     int device = 0;
     std::string err;
@@ -71,6 +90,7 @@ struct ifr_handle_s {
     void *ws_met = nullptr; size_t ws_met_bytes = 0;
     void *ws_sort = nullptr; size_t ws_sort_bytes = 0;
     double *discount = nullptr;
+    void *scratch = nullptr;     // this device's copy of the static `scratch` array (ifr_rank_topk_noalloc)
     // tuning
     int opt_chunks = 0;          // 0 = heuristic
     int opt_target_blocks = 4096;
@@ -119,12 +139,14 @@ int grow(ifr_handle h, void **p, size_t *have, size_t need)
 // as 224, k = 100 as 128, k = 50 as 64)
 int pad_k(int k) { return k <= 32 ? 32 : (k + 31) / 32 * 32; }
 
-void pick_chunks(ifr_handle h, int64_t n, int *chunk_tiles, int *n_chunks)
+// cap_chunks > 0: an upper limit on the item chunks (a fixed-size workspace holds 2 partial lists per chunk and user)
+void pick_chunks(ifr_handle h, int64_t n, int *chunk_tiles, int *n_chunks, int64_t cap_chunks = 0)
 {
     const int64_t n_ut = (n + ifr::USERS_PER_BLOCK - 1) / ifr::USERS_PER_BLOCK;
     int64_t c = h->opt_chunks > 0 ? h->opt_chunks : (h->opt_target_blocks + n_ut - 1) / n_ut;
     const int64_t max_c = std::max<int64_t>(1, std::min<int64_t>(64, h->n_tiles / 16));
     c = std::max<int64_t>(1, std::min(c, max_c));
+    if (cap_chunks > 0) c = std::min(c, cap_chunks);
     *chunk_tiles = (int)((h->n_tiles + c - 1) / c);
     *n_chunks = (h->n_tiles + *chunk_tiles - 1) / *chunk_tiles;
 }
@@ -180,12 +202,14 @@ void clear_factor_model(ifr_handle h)
     if (h->mode == MODE_FACTOR) { h->mode = MODE_NONE; h->n_items = 0; }
 }
 
-// CSR data was laid out for another catalogue: drop it rather than index out of range later
+// CSR data was laid out for another catalogue: drop it (exclusions AND truth) rather than index out of range later
 void drop_csrs_if_catalogue_changes(ifr_handle h, int64_t n_items)
 {
     if (h->n_items == n_items) return;
     dfree(h->ex_ptr); dfree(h->ex_idx); dfree(h->ex_cnt); dfree(h->ex_pair);
     h->ex_rows = 0; h->ex_nnz = 0;
+    dfree(h->tr_ptr); dfree(h->tr_idx);
+    h->tr_rows = 0; h->tr_nnz = 0; h->tr_max_row = 0;
 }
 
 // column scale padded to whole chunks (the kernels read it 16 B at a time)
@@ -237,9 +261,12 @@ int ifr_create(ifr_handle *out, int device_id)
         delete h;
         return IFR_ERR_HIP;
     }
-    if (const char *e = getenv("IFR_CHUNKS")) h->opt_chunks = atoi(e);
-    if (const char *e = getenv("IFR_DEBUG_MODE")) h->opt_debug = atoi(e);      // dev-only kernel ablation
-    if (const char *e = getenv("IFR_TARGET_BLOCKS")) h->opt_target_blocks = std::max(1, atoi(e));
+    h->scratch = scratch_of_device(device_id);
+    if (!h->scratch) {
+        (void)hipFree(h->discount);
+        delete h;
+        return IFR_ERR_HIP;
+    }
     *out = h;
     return IFR_OK;
 }
@@ -289,8 +316,12 @@ int ifr_set_factors(ifr_handle h, const float *U, int64_t n_users, const float *
     if (k > IFR_MAX_FACTORS) return fail(h, IFR_ERR_ARG, "ifr_set_factors: k > IFR_MAX_FACTORS (256)");
     if (n_items > (int64_t)1 << 30) return fail(h, IFR_ERR_ARG, "ifr_set_factors: n_items too large");
     IFR_HIP(h, hipSetDevice(h->device));
-    dfree(h->U); dfree(h->V); dfree(h->ibase); dfree(h->ubase);
+    const int64_t old_items = h->n_items;
+    clear_factor_model(h);                 // mode NONE, no users / items: a failed allocation below leaves no model set
     clear_item_model(h);
+    h->n_items = old_items;                // only for the catalogue comparison below
+    drop_csrs_if_catalogue_changes(h, n_items);
+    h->n_items = 0;
     const int KD = pad_k(k);
     const int n_tiles = (int)((n_items + ifr::TILE_I - 1) / ifr::TILE_I);
     const int64_t v_rows = (int64_t)(n_tiles + 1) * ifr::TILE_I;
@@ -307,11 +338,9 @@ int ifr_set_factors(ifr_handle h, const float *U, int64_t n_users, const float *
     if (ibase) IFR_HIP(h, hipMemcpy(h->ibase, ibase, sizeof(float) * n_items, hipMemcpyDefault));
     if (ubase) IFR_HIP(h, hipMemcpy(h->ubase, ubase, sizeof(float) * n_users, hipMemcpyDefault));
     h->has_base = (ibase != nullptr) || (ubase != nullptr);
-    drop_csrs_if_catalogue_changes(h, n_items);
     h->n_users = n_users; h->n_items = n_items; h->k = k; h->KD = KD; h->n_tiles = n_tiles;
     h->mode = MODE_FACTOR;
     h->opt_catalogue = 0;
-    // CSR data set for another catalogue size would index out of range
     return IFR_OK;
 }
 
@@ -709,8 +738,9 @@ static int rank_topk_item_item(ifr_handle h, const int32_t *user_ids, int64_t n,
 }
 
 // fused score + top-K of a dot-product model; dense != nullptr: the kernel also writes every score
+// fixed_ws != nullptr: the workspace is that buffer of fixed_bytes (nothing is allocated, no profiling events)
 static int rank_topk_factor(ifr_handle h, const int32_t *user_ids, int64_t n, int K, int KL, int32_t *out_ids, float *out_scores,
-                            float *dense, int64_t dense_ld, hipStream_t s);
+                            float *dense, int64_t dense_ld, hipStream_t s, void *fixed_ws = nullptr, size_t fixed_bytes = 0);
 
 int ifr_rank_topk(ifr_handle h, const int32_t *user_ids, int64_t n, int K, int32_t *out_ids, float *out_scores, void *stream)
 {
@@ -742,45 +772,58 @@ int ifr_rank_topk_dense(ifr_handle h, const int32_t *user_ids, int64_t n, int K,
 }
 
 static int rank_topk_factor(ifr_handle h, const int32_t *user_ids, int64_t n, int K, int KL, int32_t *out_ids, float *out_scores,
-                            float *dense, int64_t dense_ld, hipStream_t s)
+                            float *dense, int64_t dense_ld, hipStream_t s, void *fixed_ws, size_t fixed_bytes)
 {
-    int chunk_tiles, n_chunks;
-    pick_chunks(h, n, &chunk_tiles, &n_chunks);
+    if (!h->U || !h->V || h->n_users <= 0) return fail(h, IFR_ERR_STATE, "ifr_rank_topk: no user factors set");
     const int64_t n_ut = (n + ifr::USERS_PER_BLOCK - 1) / ifr::USERS_PER_BLOCK;
+    const size_t lb_bytes = (size_t)n_ut * ifr::USERS_PER_BLOCK * sizeof(uint32_t);
+    const size_t chunk_bytes = (size_t)n * 2 * KL * 8;          // two partial lists per user and item chunk
+    int64_t cap_chunks = 0;
+    if (fixed_ws) {
+        if (lb_bytes + chunk_bytes > fixed_bytes) return fail(h, IFR_ERR_ARG, "ifr_rank_topk_noalloc: batch too large for the static workspace (see IFR_NOALLOC_MAX_USERS)");
+        cap_chunks = (int64_t)((fixed_bytes - lb_bytes) / chunk_bytes);
+    }
+    int chunk_tiles, n_chunks;
+    pick_chunks(h, n, &chunk_tiles, &n_chunks, cap_chunks);
     const int64_t grid = n_ut * n_chunks;
     if (grid > (int64_t)0xffffffffu / ifr::BLOCK) return fail(h, IFR_ERR_ARG, "ifr_rank_topk: batch too large, split the user list");
     const size_t entries = (size_t)n * n_chunks * 2 * KL;
-    const size_t lb_bytes = (size_t)n_ut * ifr::USERS_PER_BLOCK * sizeof(uint32_t);
-    int rc = grow(h, &h->ws_part, &h->ws_part_bytes, entries * 8 + lb_bytes);
-    if (rc) return rc;
+    void *ws = fixed_ws;
+    if (!ws) {
+        int rc = grow(h, &h->ws_part, &h->ws_part_bytes, entries * 8 + lb_bytes);
+        if (rc) return rc;
+        ws = h->ws_part;
+    }
     ifr::TopkParams p;
     p.U = h->U; p.V = h->V; p.ibase = h->ibase; p.ubase = h->ubase;
-    p.user_ids = user_ids; p.n = n; p.n_items = (int)h->n_items; p.n_tiles = h->n_tiles;
+    p.user_ids = user_ids; p.n_users = h->n_users; p.n = n; p.n_items = (int)h->n_items; p.n_tiles = h->n_tiles;
     p.chunk_tiles = chunk_tiles; p.n_chunks = n_chunks; p.K = K;
     p.ex_ptr = h->ex_ptr; p.ex_cnt = h->ex_cnt; p.ex_pair = h->ex_pair; p.ex_rows = h->ex_rows;
     p.dbg = h->opt_debug;
     p.dense = dense; p.dense_ld = dense_ld;
     p.stamps = nullptr;
-    if (h->opt_debug & 128) {                       // dev-only phase timing, read back by ifr_debug_read_stamps
+    if ((h->opt_debug & 128) && !fixed_ws) {        // dev-only phase timing, read back by ifr_debug_read_stamps
         int rc2 = grow(h, &h->ws_met, &h->ws_met_bytes, (size_t)grid * 4 * 8 * sizeof(unsigned long long));
         if (rc2) return rc2;
         p.stamps = (unsigned long long *)h->ws_met;
         h->dbg_stamp_count = (size_t)grid * 32;
     }
-    p.part_scores = (float *)h->ws_part;
-    p.part_ids = (int32_t *)((char *)h->ws_part + entries * 4);
-    p.lb = h->opt_share_bounds ? (uint32_t *)((char *)h->ws_part + entries * 8) : nullptr;
+    p.part_scores = (float *)ws;
+    p.part_ids = (int32_t *)((char *)ws + entries * 4);
+    // the bound words start at zero on every call (the static workspace keeps the last call's contents)
+    p.lb = h->opt_share_bounds ? (uint32_t *)((char *)ws + entries * 8) : nullptr;
     if (p.lb) IFR_HIP(h, hipMemsetAsync(p.lb, 0, lb_bytes, s));
 
+    const bool prof = h->prof && !fixed_ws;
     std::pair<hipEvent_t, hipEvent_t> ev;
-    if (h->prof) {
+    if (prof) {
         if (!h->ev_free.empty()) { ev = h->ev_free.back(); h->ev_free.pop_back(); }
         else { IFR_HIP(h, hipEventCreate(&ev.first)); IFR_HIP(h, hipEventCreate(&ev.second)); }
         IFR_HIP(h, hipEventRecord(ev.first, s));
     }
     if (KL == 16) launch_topk_kd<16>(h->KD, h->has_base, p, (int)grid, s);
     else launch_topk_kd<32>(h->KD, h->has_base, p, (int)grid, s);
-    if (h->prof) {
+    if (prof) {
         IFR_HIP(h, hipEventRecord(ev.second, s));
         h->ev_used.push_back(ev);
         h->prof_pairs += (double)n * (double)h->n_items;
@@ -794,6 +837,19 @@ static int rank_topk_factor(ifr_handle h, const int32_t *user_ids, int64_t n, in
         ifr::launch_merge_topk<32>(p.part_scores, p.part_ids, n, n_chunks * 2, K, out_ids, out_scores, s);
     IFR_HIP(h, hipGetLastError());
     return IFR_OK;
+}
+
+int ifr_rank_topk_noalloc(ifr_handle h, const int32_t *user_ids, int64_t n, int K, int32_t *out_ids, float *out_scores, void *stream)
+{
+    if (!h) return IFR_ERR_ARG;
+    if (h->mode != MODE_FACTOR) return fail(h, IFR_ERR_STATE, "ifr_rank_topk_noalloc: needs a dot-product model (ifr_set_factors)");
+    if (n == 0) return IFR_OK;
+    if (!user_ids || !out_ids || !out_scores || n < 0) return fail(h, IFR_ERR_ARG, "ifr_rank_topk_noalloc: null/negative argument");
+    if (K < 1 || K > IFR_MAX_TOPK) return fail(h, IFR_ERR_ARG, "ifr_rank_topk_noalloc: K must be in [1, 32]");
+    if (n > IFR_NOALLOC_MAX_USERS) return fail(h, IFR_ERR_ARG, "ifr_rank_topk_noalloc: more than IFR_NOALLOC_MAX_USERS (65536) users in one call");
+    IFR_HIP(h, hipSetDevice(h->device));
+    return rank_topk_factor(h, user_ids, n, K, K <= 16 ? 16 : 32, out_ids, out_scores, nullptr, 0, (hipStream_t)stream,
+                            h->scratch, (size_t)IFR_NOALLOC_SCRATCH_BYTES);
 }
 
 static int sum_columns(ifr_handle h, const double *per_user, const int32_t *evaluated, int64_t n, int ncol,
@@ -916,13 +972,14 @@ int ifr_score_dense(ifr_handle h, const int32_t *user_ids, int64_t n, float *out
             return fail(h, IFR_ERR_HIP, "ifr_score_dense: item-item launch failed");
         return IFR_OK;
     }
+    if (!h->U || !h->V || h->n_users <= 0) return fail(h, IFR_ERR_STATE, "ifr_score_dense: no user factors set");
     int chunk_tiles, n_chunks;
     pick_chunks(h, n, &chunk_tiles, &n_chunks);
     const int64_t n_ut = (n + ifr::USERS_PER_BLOCK - 1) / ifr::USERS_PER_BLOCK;
     const int64_t grid = n_ut * n_chunks;
     if (grid > (int64_t)0xffffffffu / ifr::BLOCK) return fail(h, IFR_ERR_ARG, "ifr_score_dense: batch too large");
     ifr::DenseParams p;
-    p.U = h->U; p.V = h->V; p.ibase = h->ibase; p.ubase = h->ubase; p.user_ids = user_ids; p.n = n;
+    p.U = h->U; p.V = h->V; p.ibase = h->ibase; p.ubase = h->ubase; p.user_ids = user_ids; p.n_users = h->n_users; p.n = n;
     p.n_items = (int)h->n_items; p.n_tiles = h->n_tiles; p.chunk_tiles = chunk_tiles; p.n_chunks = n_chunks;
     p.out = out; p.ld = ld;
     hipStream_t s = (hipStream_t)stream;
@@ -962,6 +1019,8 @@ int ifr_rank_full(ifr_handle h, const int32_t *user_ids, int64_t n, const float 
     if (n == 0) return IFR_OK;
     const int64_t cat = catalogue_items(h);
     if (!user_ids || !scores || !out_ids || !n_cand || n < 0 || ld < cat) return fail(h, IFR_ERR_ARG, "ifr_rank_full: bad argument");
+    if ((uint64_t)n * (uint64_t)cat > 0xffffffffull)
+        return fail(h, IFR_ERR_ARG, "ifr_rank_full: more than 2^32 - 1 (user, item) pairs in one call, split the user list");
     IFR_HIP(h, hipSetDevice(h->device));
     int rc = ifr::launch_rank_full(scores, ld, user_ids, n, (int)cat, h->ex_ptr, h->ex_idx, h->ex_rows, out_ids,
                                    n_cand, &h->ws_sort, &h->ws_sort_bytes, (hipStream_t)stream);

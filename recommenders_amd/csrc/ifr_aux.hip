@@ -35,17 +35,38 @@ __global__ __launch_bounds__(AUC_BLOCK) void auc_kernel(const float *scores, int
     const int u = user_ids[i];
     const float *row = scores + i * ld;
     int64_t tb = 0, te = 0, eb = 0, ee = 0;
-    if (u < tr_rows) { tb = tr_ptr[u]; te = tr_ptr[u + 1]; }
-    if (ex_ptr != nullptr && u < ex_rows) { eb = ex_ptr[u]; ee = ex_ptr[u + 1]; }
-    const int n_pos = (int)(te - tb);
+    __shared__ int s_bad;
+    if (u >= 0 && u < tr_rows) { tb = tr_ptr[u]; te = tr_ptr[u + 1]; }
+    if (ex_ptr != nullptr && u >= 0 && u < ex_rows) { eb = ex_ptr[u]; ee = ex_ptr[u + 1]; }
+    const int n_row = (int)(te - tb);
+    if (n_row == 0) {
+        if (threadIdx.x == 0) out[i] = __longlong_as_double(0x7ff8000000000000LL);
+        return;
+    }
+    if (threadIdx.x == 0) s_bad = 0;
+    __syncthreads();
+    int np2 = 1;
+    while (np2 < n_row) np2 <<= 1;
+    // truth entries outside the catalogue are absent, as in metrics_dense_kernel: they sort last as +inf pads and
+    // leave n_pos, so they are never read, never win and never count as positives
+    {
+        int bad = 0;
+        for (int q = threadIdx.x; q < np2; q += AUC_BLOCK) {
+            float v = INFINITY;
+            if (q < n_row) {
+                const int it = tr_idx[tb + q];
+                if (it >= 0 && it < n_items) v = row[it]; else ++bad;
+            }
+            ps[q] = v;
+        }
+        if (bad) atomicAdd(&s_bad, bad);
+    }
+    __syncthreads();
+    const int n_pos = n_row - s_bad;
     if (n_pos == 0) {
         if (threadIdx.x == 0) out[i] = __longlong_as_double(0x7ff8000000000000LL);
         return;
     }
-    int np2 = 1;
-    while (np2 < n_pos) np2 <<= 1;
-    for (int q = threadIdx.x; q < np2; q += AUC_BLOCK) ps[q] = q < n_pos ? row[tr_idx[tb + q]] : INFINITY;
-    __syncthreads();
     // bitonic sort ascending in LDS
     for (int k = 2; k <= np2; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
@@ -148,7 +169,7 @@ __global__ void kill_excluded_kernel(const int32_t *user_ids, int n_items, const
     const int64_t i = blockIdx.x;
     const int u = user_ids[i];
     int64_t eb = 0, ee = 0;
-    if (ex_ptr != nullptr && u < ex_rows) { eb = ex_ptr[u]; ee = ex_ptr[u + 1]; }
+    if (ex_ptr != nullptr && u >= 0 && u < ex_rows) { eb = ex_ptr[u]; ee = ex_ptr[u + 1]; }
     int c = 0;
     for (int64_t q = eb + threadIdx.x; q < ee; q += blockDim.x) {
         const int it = ex_idx[q];
@@ -216,6 +237,7 @@ int launch_rank_full(const float *scores, int64_t ld, const int32_t *user_ids, i
                      const int64_t *ex_ptr, const int32_t *ex_idx, int64_t ex_rows, int32_t *out_ids, int32_t *n_cand,
                      void **ws, size_t *ws_bytes, hipStream_t stream)
 {
+    if ((size_t)n * (size_t)n_items > 0xffffffffull) return -1;      // rocPRIM's segmented sort takes a 32-bit pair count
     const size_t key_bytes = sizeof(uint64_t) * (size_t)n * n_items;
     auto offs = rocprim::make_transform_iterator(rocprim::make_counting_iterator<int64_t>(0), row_offsets{n_items});
     size_t tmp_bytes = 0;

@@ -32,7 +32,9 @@ constexpr int NO_TILE = 0x7fffffff;
 
 struct TopkParams {
     const float *U, *V, *ibase, *ubase;
-    const int32_t *user_ids;
+    const int32_t *user_ids; // rows of U; ids outside [0, n_users) are clamped into it (no out-of-bounds read; the
+                             // host mirror rejects them before the call)
+    int64_t n_users;
     int64_t n;               // users in this batch
     int n_items;
     int n_tiles;             // ceil(n_items / 32)
@@ -136,7 +138,7 @@ __global__ __launch_bounds__(BLOCK, KD > 128 ? 1 : 2) void score_topk_kernel(Top
 
     const int64_t slot = (int64_t)ut * USERS_PER_BLOCK + wave * 32 + j;
     const bool live = slot < p.n;
-    const int uid = p.user_ids[live ? slot : p.n - 1];
+    const int uid = (int)min((int64_t)max(p.user_ids[live ? slot : p.n - 1], 0), p.n_users - 1);
 
     // user factors: lane (j,h) keeps U[uid][8g + 4h + e], g < KD/8, e < 4
     f32x4 ureg[KD / 8];
@@ -504,7 +506,8 @@ inline void launch_merge_topk(const float *part_scores, const int32_t *part_ids,
 // ------------------------------------------------------------------------------------
 struct DenseParams {
     const float *U, *V, *ibase, *ubase;
-    const int32_t *user_ids;
+    const int32_t *user_ids;     // clamped into [0, n_users) like TopkParams::user_ids
+    int64_t n_users;
     int64_t n;
     int n_items, n_tiles, chunk_tiles, n_chunks;
     float *out;
@@ -530,7 +533,7 @@ __global__ __launch_bounds__(BLOCK, 2) void score_dense_kernel(DenseParams p)
 
     const int64_t slot0 = (int64_t)ut * USERS_PER_BLOCK + wave * 32;
     const int64_t slot = slot0 + j;
-    const int uid = p.user_ids[slot < p.n ? slot : p.n - 1];
+    const int uid = (int)min((int64_t)max(p.user_ids[slot < p.n ? slot : p.n - 1], 0), p.n_users - 1);
     f32x4 ureg[KD / 8];
     {
         const float *up = p.U + (int64_t)uid * KD + 4 * h;
@@ -541,7 +544,7 @@ __global__ __launch_bounds__(BLOCK, 2) void score_dense_kernel(DenseParams p)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int64_t sl = slot0 + acc_row(r, h);
-        ubr[r] = HAS_BASE ? p.ubase[p.user_ids[sl < p.n ? sl : p.n - 1]] : 0.0f;
+        ubr[r] = HAS_BASE ? p.ubase[min((int64_t)max(p.user_ids[sl < p.n ? sl : p.n - 1], 0), p.n_users - 1)] : 0.0f;
     }
 
     f32x4 st[STAGE];

@@ -89,6 +89,26 @@ class HipScorer:
             return x.to(device=self.device, dtype=torch.int32).contiguous()
         return torch.from_numpy(np.ascontiguousarray(x, dtype=np.int32)).to(self.device)
 
+    def _dev_users(self, x):
+        """int32 device tensor of user rows, checked against [0, n_users): the reference indexes its parameter arrays
+        with the user index and raises IndexError beyond them; the kernels only clamp.  The check of a device tensor
+        costs one small reduction + sync, skipped when the same tensor (storage, length, version) was checked last."""
+        torch = _torch()
+        if isinstance(x, torch.Tensor) and x.is_cuda:
+            u = x.to(device=self.device, dtype=torch.int32).contiguous()
+            key = (u.data_ptr(), u.numel(), getattr(x, "_version", None), self.n_users)
+            if u.numel() and key != getattr(self, "_users_checked", None):
+                lo, hi = (int(v) for v in torch.aminmax(x))
+                if lo < 0 or hi >= self.n_users:
+                    raise IndexError(f"user index {lo if lo < 0 else hi} is out of bounds for {self.n_users} user rows")
+                self._users_checked = key
+            return u
+        a = np.asarray(x.numpy() if isinstance(x, torch.Tensor) else x)
+        if a.size and (int(a.min()) < 0 or int(a.max()) >= self.n_users):
+            bad = int(a.min()) if int(a.min()) < 0 else int(a.max())
+            raise IndexError(f"user index {bad} is out of bounds for {self.n_users} user rows")
+        return torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32)).to(self.device)
+
     def set_option(self, name, value):
         self._check(self._lib.ifr_set_option(self._h, name.encode(), int(value)))
 
@@ -230,7 +250,7 @@ class HipScorer:
         """Top-K (ids int32 [n,K], scores fp32 [n,K]) for the listed users: the fused kernel up to K = 32, dense rows +
         partial ranking up to K = 1024 (`dense_batch_pairs` bounds users x items of one dense batch)."""
         torch = _torch()
-        u = self._dev_i32(user_ids)
+        u = self._dev_users(user_ids)
         n = u.numel()
         if out_ids is None:
             out_ids = torch.empty((n, K), dtype=torch.int32, device=self.device)
@@ -250,6 +270,25 @@ class HipScorer:
             self.select_topk(ub, dense, K, out_ids[b:b + step], out_scores[b:b + step])
         return out_ids, out_scores
 
+    NOALLOC_MAX_USERS = 65536     # ifr_rank_topk_noalloc (IFR_NOALLOC_MAX_USERS)
+
+    def rank_topk_noalloc(self, user_ids, K, out_ids, out_scores):
+        """ifr_rank_topk_noalloc: rank_topk for callers that cannot allocate (HIP graph capture, serving loops).  The
+        library call allocates nothing -- its workspace is a static device array -- so `user_ids` (int32 device tensor)
+        and both outputs must be the caller's own preallocated device tensors.  Dot-product models, K <= 32,
+        at most NOALLOC_MAX_USERS users per call; calls that overlap on one GPU race (include/ifr.h).  User rows
+        are not range-checked here (the check would allocate); the kernel clamps them into [0, n_users)."""
+        torch = _torch()
+        for t, dt in ((user_ids, torch.int32), (out_ids, torch.int32), (out_scores, torch.float32)):
+            if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == dt and t.is_contiguous()):
+                raise ValueError("rank_topk_noalloc: user_ids / out_ids / out_scores must be contiguous device tensors (int32, int32, float32)")
+        n = user_ids.numel()
+        if tuple(out_ids.shape) != (n, int(K)) or tuple(out_scores.shape) != (n, int(K)):
+            raise ValueError("rank_topk_noalloc: outputs must be [n, K]")
+        self._check(self._lib.ifr_rank_topk_noalloc(self._h, user_ids.data_ptr(), n, int(K), out_ids.data_ptr(),
+                                                    out_scores.data_ptr(), self._stream()))
+        return out_ids, out_scores
+
     MAX_TOPK_WITH_DENSE = 32      # ifr_rank_topk_dense (= IFR_MAX_TOPK)
 
     def can_rank_topk_dense(self, K):
@@ -262,7 +301,7 @@ class HipScorer:
         """rank_topk and score_dense in one launch (one GEMM instead of two): returns (ids [n,K], scores [n,K],
         dense [n, n_items] view).  The dense buffer has rows of n_items rounded up to 32 floats."""
         torch = _torch()
-        u = self._dev_i32(user_ids)
+        u = self._dev_users(user_ids)
         n = u.numel()
         ld = (self.n_items + 31) // 32 * 32
         if dense is None:
@@ -356,10 +395,16 @@ class HipScorer:
         self._check(self._lib.ifr_set_option(self._h, b"catalogue_items", 0 if n_total == self.n_items else n_total))
         self.catalogue_items = max(n_total, self.n_items)
 
+    def new_score_rows(self, n_rows):
+        """An uninitialised [n_rows, catalogue] fp32 buffer for score_dense(out=...): callers that loop over batches
+        allocate it once (two live buffers would double the footprint the batch size was chosen for)."""
+        cols = max(getattr(self, "catalogue_items", 0), self.n_items)
+        return _torch().empty((int(n_rows), cols), dtype=_torch().float32, device=self.device)
+
     def score_dense(self, user_ids, out=None):
         """Score rows [n, catalogue] (catalogue = n_items unless set_catalogue_items widened it)."""
         torch = _torch()
-        u = self._dev_i32(user_ids)
+        u = self._dev_users(user_ids)
         n = u.numel()
         cols = max(getattr(self, "catalogue_items", 0), self.n_items)
         if out is None:

@@ -160,15 +160,27 @@ def cache_rankings(model, user_idx, item_indices, k=-1):
     return item_rank, item_scores
 
 
-def _rows_that_fit(eng, want_rows, row_floats):
-    """Dense score rows per batch: what the caller's bound asks for, at most half of the free device memory."""
+def _free_device_bytes(eng):
+    """Bytes the next allocations may take on the engine's device (None on a CPU stand-in)."""
+    if hasattr(eng, "free_bytes"):
+        return eng.free_bytes()
     dev = getattr(eng, "device", None)
     if dev is None or getattr(dev, "type", "cpu") != "cuda":
-        return max(1, int(want_rows))
+        return None
     import torch
     free, _ = torch.cuda.mem_get_info(dev)
     reusable = torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)     # cached blocks torch can hand out again
-    return max(1, min(int(want_rows), int((free + reusable) // 2) // (4 * int(row_floats))))
+    return int(free + reusable)
+
+
+def _rows_that_fit(eng, want_rows, row_bytes):
+    """Dense score rows per batch: what the caller's bound asks for, at most half of the free device memory.
+    `row_bytes` = every byte one row of the chosen branch keeps on the device at a time (the fp32 row, and for the
+    sorted-list branch its id row, two 64-bit sort keys per item and the sort's temporary storage)."""
+    free = _free_device_bytes(eng)
+    if free is None:
+        return max(1, int(want_rows))
+    return max(1, min(int(want_rows), (free // 2) // int(row_bytes)))
 
 
 def export_candidate_pools(model, pool_size, batch_users=1 << 16, _engine=None):
@@ -340,7 +352,7 @@ def ranking_eval(model, metrics, train_set, test_set, val_set=None, rating_thres
             kmax = max(ks)
             if fused_dense:
                 ld = (n_items + 31) // 32 * 32
-                step = _rows_that_fit(eng, min(n, int((batch_pairs or 1 << 32) // ld)), ld)
+                step = _rows_that_fit(eng, min(n, int((batch_pairs or 1 << 32) // ld)), 4 * ld)
                 ids = torch.empty((n, kmax), dtype=torch.int32, device=eng.device)
                 rows = torch.empty((step, ld), dtype=torch.float32, device=eng.device)
                 auc = np.empty(n)
@@ -366,13 +378,20 @@ def ranking_eval(model, metrics, train_set, test_set, val_set=None, rating_thres
             dense_metrics = max_pos <= MAX_DENSE_METRIC_POS
             # rows only (counting metrics, AUC): 16 GB batches, large launches run 20 % faster per user than 1 GB
             # ones; the sorted-list fallback also holds 64-bit sort keys and ids per pair, so it keeps 2^28 pairs
-            default_pairs = 1 << 32 if (dense_metrics or not need_list) else 1 << 28
-            step = _rows_that_fit(eng, (batch_pairs or default_pairs) // max(1, n_items), n_items)
+            sorted_lists = need_list and not dense_metrics
+            default_pairs = 1 << 28 if sorted_lists else 1 << 32
+            # per row and item: 4 B of scores; the sorted-list branch adds 4 B of ranked ids, 16 B of sort keys (in and
+            # out) and rocPRIM's temporary storage (below 4 B per item)
+            row_bytes = (4 + (24 if sorted_lists else 0)) * n_items
+            step = _rows_that_fit(eng, min(n, (batch_pairs or default_pairs) // max(1, n_items)), row_bytes)
+            if sorted_lists:
+                step = max(1, min(step, (2 ** 32 - 1) // max(1, n_items)))        # ifr_rank_full: 32-bit pair count
             per_list = np.empty((n, METRICS_PER_K * len(lst_ks) + 2)) if need_list else None
             auc = np.empty(n) if need_auc else None
+            rows = eng.new_score_rows(step) if hasattr(eng, "new_score_rows") else None     # ONE buffer for every batch
             for b in range(0, n, step):
                 bu = dev_users[b:b + step]
-                dense = eng.score_dense(bu)
+                dense = eng.score_dense(bu) if rows is None else eng.score_dense(bu, rows[: len(bu)])
                 if need_auc:
                     auc[b:b + step] = eng.auc_dense(bu, dense).cpu().numpy()
                 if need_list and dense_metrics:
@@ -383,6 +402,7 @@ def ranking_eval(model, metrics, train_set, test_set, val_set=None, rating_thres
                     ranked, n_cand = eng.rank_full(bu, dense)
                     pl, _, _ = eng.eval_ranked_metrics(bu, ranked, n_cand, lst_ks)
                     per_list[b:b + step] = pl.cpu().numpy()
+            del rows
             if need_list:
                 for qi, k in enumerate(lst_ks):
                     for ci, name in enumerate(METRIC_COLUMNS):

@@ -249,6 +249,11 @@ class HipScoringMixin:
             if (rows != users).any():
                 raise ValueError("rank_batch: exclusions need user rows that exist in the model")
             eng.set_exclusion_csr(np.asarray(ptr, np.int64), np.asarray(idx, np.int32))
+        elif getattr(eng, "has_exclusions", False) or getattr(eng, "exclusion_source", None) is not None:
+            # nothing is excluded unless a CSR is passed: drop what an earlier ranking_eval / export left installed
+            eng.set_exclusion_csr(np.zeros(1, np.int64), np.zeros(0, np.int32))
+        if getattr(eng, "catalogue_items", eng.n_items) != eng.n_items:
+            eng.set_catalogue_items(eng.n_items)      # rank the model's own items, not an evaluation's widened catalogue
         ids, scores = eng.rank_topk(rows.astype(np.int32), int(k))
         return ids.cpu().numpy(), scores.cpu().numpy()
 
@@ -287,7 +292,12 @@ class BPR(HipScoringMixin, RecommenderBase):
         return np.concatenate([v, np.asarray(self.i_biases, np.float32).reshape(-1, 1)], axis=1) if self.use_bias else v
 
     def _hip_user_row(self, user_idx):
-        return int(user_idx)            # factors are allocated for total_users (recom_bpr.pyx:146-151)
+        # factors are allocated for total_users (recom_bpr.pyx:146-151); the reference indexes u_factors[user_idx]
+        # (:290): IndexError beyond the array, NumPy's wrap-around for a negative index inside it
+        n = len(self.u_factors)
+        if not -n <= int(user_idx) < n:
+            raise IndexError(f"index {int(user_idx)} is out of bounds for axis 0 with size {n}")
+        return int(user_idx) % n
 
 
 class MF(HipScoringMixin, RecommenderBase):

@@ -129,3 +129,50 @@ def make_item(name, n_users=None, n_items=None, seed=None, device=None, row_nnz=
         with np.errstate(divide="ignore"):
             out["col_scale"] = (1.0 / np.maximum(deg, 1.0) ** 0.7).astype(np.float32)
     return out
+
+
+# ---------------------------------------------------------------------------- C3 on the device
+def make_c3_device(n_users=None, n_items=None, seed=None, device=None, per_user=60, n_test=10):
+    """configs[2] shard generated on the GPU (torch tensors on `device`): 1.25 M users x 60 interactions take minutes
+    with the NumPy generator above and seconds here.  Factors and biases as in `factor_model`; every user has
+    `per_user` distinct items, one drawn uniformly from each of `per_user` equal strata of the catalogue (ascending
+    by construction, no duplicates), `n_test` of them at random held out as the truth row, the rest the exclusion row
+    ("about 50 train + 10 test items per user").  Item popularity is uniform, not Zipf: the
+    fused kernel's cost does not depend on which items are excluded."""
+    import torch
+    nu, ni, k, _, sd, _ = CONFIGS["c3_mf_shard"]
+    nu = nu if n_users is None else n_users
+    ni = ni if n_items is None else n_items
+    g = torch.Generator(device=device)
+    g.manual_seed(sd if seed is None else seed)
+    f32 = dict(dtype=torch.float32, device=device)
+    U = torch.empty((nu, k), **f32).normal_(0, 0.1, generator=g)
+    V = torch.empty((ni, k), **f32).normal_(0, 0.1, generator=g)
+    ubase = torch.empty((nu,), **f32).normal_(0, 0.01, generator=g)
+    ibase = torch.empty((ni,), **f32).normal_(0, 0.01, generator=g)
+    per_user = min(per_user, ni)
+    n_test = min(n_test, per_user - 1)
+    width = ni // per_user
+    base = torch.arange(per_user, device=device, dtype=torch.int64) * width
+    items = base[None, :] + (torch.rand((nu, per_user), generator=g, device=device) * width).long().clamp_(max=width - 1)
+    pick = torch.rand((nu, per_user), generator=g, device=device).argsort(dim=1)[:, :n_test]
+    is_test = torch.zeros((nu, per_user), dtype=torch.bool, device=device)
+    is_test.scatter_(1, pick, True)
+    truth_idx = items[is_test].to(torch.int32)                       # row-major order: ascending inside a row
+    excl_idx = items[~is_test].to(torch.int32)
+    n_ex = per_user - n_test
+    return dict(name="c3_mf_shard", n_users=nu, n_items=ni, k=k, U=U, V=V, ubase=ubase, ibase=ibase,
+                excl_ptr=torch.arange(nu + 1, dtype=torch.int64) * n_ex, excl_idx=excl_idx,
+                truth_ptr=torch.arange(nu + 1, dtype=torch.int64) * n_test, truth_idx=truth_idx)
+
+
+def host_sample(dw, m):
+    """NumPy copies of what a CPU checker needs for the first m users of a device workload (all of V, m rows of U
+    and of the CSRs); n_users stays the full count, `host_rows` = m."""
+    m = int(min(m, dw["n_users"]))
+    e_end, t_end = int(dw["excl_ptr"][m]), int(dw["truth_ptr"][m])
+    cpu = lambda t: t.cpu().numpy()
+    return dict(name=dw["name"], n_users=dw["n_users"], n_items=dw["n_items"], k=dw["k"], host_rows=m,
+                U=cpu(dw["U"][:m]), V=cpu(dw["V"]), ubase=cpu(dw["ubase"][:m]), ibase=cpu(dw["ibase"]),
+                excl_ptr=cpu(dw["excl_ptr"][: m + 1]), excl_idx=cpu(dw["excl_idx"][:e_end]),
+                truth_ptr=cpu(dw["truth_ptr"][: m + 1]), truth_idx=cpu(dw["truth_idx"][:t_end]))

@@ -51,8 +51,18 @@ class OracleEngine:
             s = np.concatenate([s, np.full(self.catalogue_items - self.n_items, s.min(), s.dtype)])
         return s
 
-    def score_dense(self, user_ids):
-        return torch.from_numpy(np.stack([self._padded(int(u)) for u in np.asarray(user_ids)]))
+    def new_score_rows(self, n_rows):
+        self.row_buffers = getattr(self, "row_buffers", 0) + 1
+        self.largest_row_buffer = max(getattr(self, "largest_row_buffer", 0), int(n_rows))
+        return torch.empty((int(n_rows), self.catalogue_items), dtype=torch.float32)
+
+    def score_dense(self, user_ids, out=None):
+        rows = torch.from_numpy(np.stack([self._padded(int(u)) for u in np.asarray(user_ids)]))
+        if out is None:
+            self.fresh_dense = getattr(self, "fresh_dense", 0) + 1
+            return rows
+        out[: len(rows)] = rows
+        return out[: len(rows)]
 
     def rank_topk(self, user_ids, K):
         users = np.asarray(user_ids)

@@ -365,3 +365,43 @@ def test_topk_metrics_with_auc_share_one_scoring_pass(toy):
         ref_auc = d[f"{name}__per_user"][:, list(d["metric_names"]).index("auc@-1")]
         got = np.asarray([fused[1][int(u)] for u in users])
         assert np.abs(got - ref_auc).max() < 1e-4 and abs(got.mean() - ref_auc.mean()) < 1e-6
+
+
+def test_user_indices_outside_the_model_raise_like_the_reference(toy):
+    """a user row outside the factor arrays must never reach the kernels as an address."""
+    d = toy
+    train_set, _, _ = _sets(d)
+    bpr = _model(d, "bpr", train_set)
+    n = len(bpr.u_factors)
+    for bad in (10 ** 7, n, -n - 1):
+        with pytest.raises(IndexError):
+            bpr.score(bad)
+        with pytest.raises(IndexError):
+            bpr.rank(bad)
+        with pytest.raises(IndexError):
+            bpr.rank_batch([0, bad], 5)
+    np.testing.assert_array_equal(bpr.score(-1), bpr.score(n - 1))          # NumPy's wrap-around, as u_factors[-1]
+    eng = bpr._hip_engine()
+    import torch
+    for ids in (np.array([0, eng.n_users], np.int64), torch.tensor([3, -1], device=eng.device)):
+        with pytest.raises(IndexError):
+            eng.rank_topk(ids, 5)
+        with pytest.raises(IndexError):
+            eng.score_dense(ids)
+    mf = _model(d, "mf", train_set)          # MF: an unknown user keeps mu + Bi whatever the index (recom_mf.py:277-280)
+    np.testing.assert_array_equal(mf.score(10 ** 7), mf.score(mf.num_users + 1))
+
+
+def test_rank_batch_after_ranking_eval_excludes_nothing(toy):
+    """ranking_eval leaves its exclusion CSR on the model's engine; rank_batch without exclude_csr must not
+    inherit it."""
+    d = toy
+    train_set, test_set, val_set = _sets(d)
+    model = _model(d, "bpr", train_set)
+    users = np.arange(20)
+    before, _ = model.rank_batch(users, 10)
+    ranking_eval(model, [M.NDCG(k=10)], train_set, test_set, val_set=val_set, rating_threshold=float(d["rating_threshold"]))
+    after, _ = model.rank_batch(users, 10)
+    np.testing.assert_array_equal(before, after)
+    seen = train_set.csr_matrix
+    assert any(np.isin(after[r], seen[int(u)].indices).any() for r, u in enumerate(users)), "fixture has no seen item in any head"

@@ -418,3 +418,75 @@ def test_merge_kernels_over_list_counts(torch, K):
         ids, scores = sc.rank_topk(users, K)
         np.testing.assert_array_equal(ids.cpu().numpy(), o_ids, err_msg=f"chunks={chunks}")
         np.testing.assert_array_equal(scores.cpu().numpy(), o_sc, err_msg=f"chunks={chunks}")
+
+
+def test_stale_or_out_of_range_truth_rows_are_safe(torch):
+    """ifr_auc_dense must treat truth entries outside the catalogue as absent (like ifr_eval_dense_metrics),
+    and a truth CSR uploaded for a larger catalogue must not survive a model with fewer items."""
+    from recommenders_amd.engine import IfrError
+    w = _workload(21, 64, 900, 32, False)
+    sc = _scorer(w, truth=False)
+    users = np.arange(w["n_users"], dtype=np.int32)
+    # truth rows with entries beyond the catalogue and negative ones mixed into the valid positives
+    ptr, idx = [0], []
+    for u in range(w["n_users"]):
+        good = w["truth_idx"][w["truth_ptr"][u]: w["truth_ptr"][u + 1]]
+        row = np.concatenate([[-5], good, [w["n_items"], w["n_items"] + 70000]]).astype(np.int32) if u % 2 else good
+        idx.append(row)
+        ptr.append(ptr[-1] + len(row))
+    sc.set_truth_csr(np.asarray(ptr, np.int64), np.concatenate(idx).astype(np.int32))
+    dense = sc.score_dense(users)
+    got = sc.auc_dense(users, dense).cpu().numpy()
+    sc.set_truth_csr(w["truth_ptr"], w["truth_idx"])
+    want = sc.auc_dense(users, dense).cpu().numpy()
+    np.testing.assert_array_equal(got, want)
+    # a smaller catalogue drops the truth CSR with the exclusions: the metric entry points refuse instead of reading it
+    small = _workload(22, 64, 300, 32, False)
+    sc.set_factors(small["U"], small["V"])
+    with pytest.raises(IfrError, match="truth CSR not set"):
+        sc.auc_dense(users, sc.score_dense(users))
+
+
+def test_target_shape_one_million_items_bit_exact(torch):
+    """BASELINE configs[2] (C3) shape on the item axis: 1,000,000 items, k = 128, biases (MF), top-10, a ragged batch of
+    users, exclusions that hit the first, a middle and the last item tile.  31,250 item tiles per sweep: the regime of
+    one item chunk per workgroup column and byte offsets near 2^29.  Ids and scores bit-exact against the C oracle."""
+    n_users, n_items, k, K = 300, 1_000_000, 128, 10
+    rng = np.random.default_rng(3)
+    from recommenders_amd import synth
+    U, V, ub, ib = synth.factor_model(rng, n_users, n_items, k, True)
+    rows = []
+    for u in range(n_users):
+        r = rng.choice(n_items, 50, replace=False)
+        if u % 3 == 0:
+            r = np.concatenate([r, [0, 1, 31, 500_000, 500_017, n_items - 32, n_items - 1]])
+        rows.append(np.unique(r).astype(np.int32))
+    ex_ptr = np.cumsum([0] + [len(r) for r in rows]).astype(np.int64)
+    ex_idx = np.concatenate(rows)
+    te_ptr = np.arange(n_users + 1, dtype=np.int64) * 10
+    te_idx = np.sort(rng.integers(0, n_items, (n_users, 10)).astype(np.int32), axis=1).ravel()
+    w = dict(U=U, V=V, ubase=ub, ibase=ib, excl_ptr=ex_ptr, excl_idx=ex_idx, truth_ptr=te_ptr, truth_idx=te_idx,
+             n_users=n_users, n_items=n_items, k=k)
+    # make the excluded border items the best ones of their users, so a missed exclusion would show in the list
+    V[[0, 31, 500_000, n_items - 1]] *= 4.0
+    sc = _scorer(w)
+    users = np.arange(n_users - 37, dtype=np.int32)[::-1].copy()           # 263 users: two full tiles + a ragged one
+    ids, scores = sc.rank_topk(users, K)
+    per_user, evaluated, sums = sc.eval_topk_metrics(users, ids, [K])
+    o_ids, o_sc, o_met, o_ev = _oracle(w, users, [K], K, sc.chain_order())
+    np.testing.assert_array_equal(ids.cpu().numpy(), o_ids)
+    np.testing.assert_array_equal(scores.cpu().numpy(), o_sc)
+    np.testing.assert_allclose(per_user.cpu().numpy()[:, :3], o_met[:, :3], atol=1e-12)
+    for chunks in (1, 7):                                                   # placement independent at this size too
+        sc.set_option("chunks", chunks)
+        ids2, scores2 = sc.rank_topk(users, K)
+        np.testing.assert_array_equal(ids2.cpu().numpy(), o_ids)
+        np.testing.assert_array_equal(scores2.cpu().numpy(), o_sc)
+    sc.set_option("chunks", 0)
+    # the same launch also writing the score rows (ifr_rank_topk_dense) on a few users, against ifr_score_dense
+    few = users[:5]
+    ids3, scores3, dense = sc.rank_topk_dense(few, K)
+    np.testing.assert_array_equal(ids3.cpu().numpy(), o_ids[:5])
+    np.testing.assert_array_equal(dense.cpu().numpy(), sc.score_dense(few).cpu().numpy())
+    o_dense = orc.c_score_factor(U[few[0]], V, ib, float(ub[few[0]]), sc.chain_order()[sc.chain_order() < k])
+    np.testing.assert_array_equal(dense[0].cpu().numpy(), o_dense)

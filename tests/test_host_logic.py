@@ -385,3 +385,26 @@ def test_list_metrics_fall_back_to_sorted_lists_for_very_long_truth_rows(toy, mo
     b_avg, b_usr = ifr_eval.ranking_eval(types.SimpleNamespace(is_fitted=True), mets, train_set, test_set, val_set, _engine=eng, **kw)
     np.testing.assert_allclose(a_avg, b_avg, rtol=0, atol=1e-12)
     assert a_usr[3] == pytest.approx(b_usr[3], abs=1e-12)
+
+
+def test_dense_row_batches_reuse_one_buffer_when_memory_is_short(toy):
+    """the dense-row loop (AUC, k = -1, MRR / MAP) must hold ONE row buffer however many batches it runs,
+    sized from the bytes a row of the chosen branch really keeps on the device."""
+    d = toy
+    train_set, test_set, val_set = _datasets(d)
+    fake = types.SimpleNamespace(is_fitted=True)
+    mets = [M.NDCG(k=-1), M.AUC(), M.MRR()]
+    ref_eng = _engine(d, "bpr", test_set.num_users)
+    ref_avg, ref_per = ifr_eval.ranking_eval(fake, mets, train_set, test_set, val_set,
+                                             rating_threshold=float(d["rating_threshold"]), _engine=ref_eng)
+    n_items = int(d["num_items"])
+    eng = _engine(d, "bpr", test_set.num_users)
+    eng.free_bytes = lambda: 2 * 7 * 4 * n_items            # half of it = seven fp32 rows
+    avg, per = ifr_eval.ranking_eval(types.SimpleNamespace(is_fitted=True), mets, train_set, test_set, val_set,
+                                     rating_threshold=float(d["rating_threshold"]), _engine=eng)
+    assert eng.row_buffers == 1 and eng.largest_row_buffer == 7 and getattr(eng, "fresh_dense", 0) == 0
+    assert avg == pytest.approx(ref_avg, abs=1e-12)
+    assert per[0] == ref_per[0] and per[1] == ref_per[1]
+    # the sorted-list branch keeps 28 bytes per (row, item): the same memory holds a quarter... one row here
+    assert ifr_eval._rows_that_fit(eng, 1000, 28 * n_items) == 1
+    assert ifr_eval._rows_that_fit(eng, 3, 4 * n_items) == 3

@@ -6,7 +6,7 @@ TAG=${1:-r01}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-B="$GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --no-cpu"
+B="$GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --no-cpu --no-extra"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $B > $OUT/trace.log 2>&1 || exit 1
 timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python3 $B > $OUT/pmc_fetch.log 2>&1 || exit 2
 timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- python3 $B > $OUT/pmc_write.log 2>&1 || exit 3
