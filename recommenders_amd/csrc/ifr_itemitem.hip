@@ -285,6 +285,13 @@ __global__ __launch_bounds__(II_BLOCK, 3) void item_item_kernel(ItemItemParams p
 //                when the list ends up short or holds scores <= 0; only then a second sweep marks
 //                the touched columns per chunk and takes the K lowest untouched item ids.
 // ------------------------------------------------------------------------------------
+// make ABLATE=1 compiles the cumulative early exits (option "debug_mode" 101..105, timing only, tools/time_c5.py) into
+// item_sparse_topk_kernel; the product build leaves them out (they cost SGPRs and a scratch slot)
+#ifdef IFR_ABLATE
+constexpr bool SP_DEV = true;
+#else
+constexpr bool SP_DEV = false;
+#endif
 constexpr int SP_CHUNK = II_SPARSE_PASSES * II_PASS;   // 4096 columns: granularity of cptr
 constexpr int SP_BLOCK = 512;                           // threads per user: three workgroups (6 waves/SIMD, <= 85 VGPRs) per CU
 constexpr int SP_SPT = 7;                               // hash slots per thread
@@ -475,7 +482,7 @@ __global__ __launch_bounds__(SP_BLOCK, 6) void item_sparse_topk_kernel(ItemItemP
     // qkey[0, cnt) = the list, qkey[cnt, s_nq) = new keys -> the new list; call after a barrier
     auto rank_merge = [&]() {
         const int total = s_nq, cnt = s_cnt;
-        if (total > cnt && p.dbg != 105) {
+        if (total > cnt && !(SP_DEV && p.dbg == 105)) {
             for (int e0 = 0; e0 < total; e0 += SP_NG) {
                 const int e = e0 + g;
                 const unsigned long long k = e < total ? qkey[e] : ~0ull;
@@ -511,7 +518,7 @@ __global__ __launch_bounds__(SP_BLOCK, 6) void item_sparse_topk_kernel(ItemItemP
     }
     __syncthreads();
 
-    if (p.dbg == 101) return;                             // dev ablation 101..105: cumulative early exits, timing only
+    if (SP_DEV && p.dbg == 101) return;                   // dev ablation 101..105: cumulative early exits, timing only
     // equal shares: ceil(total / cap) passes of about total / passes entries keep the table load even
     unsigned long long cap = (unsigned long long)p.sp_cap;
     {
@@ -548,7 +555,7 @@ __global__ __launch_bounds__(SP_BLOCK, 6) void item_sparse_topk_kernel(ItemItemP
                 }
             });
             walk(ca, cb, [&](const int (&c)[4], const float (&w)[4], const bool (&ok)[4], double x) {
-                if (p.dbg == 102) { if (c[0] + c[1] + c[2] + c[3] + __float_as_int(w[0] + w[1] + w[2] + w[3]) == 0x7ffffff1) vals[0] = 1ull; return; }
+                if (SP_DEV && p.dbg == 102) { if (c[0] + c[1] + c[2] + c[3] + __float_as_int(w[0] + w[1] + w[2] + w[3]) == 0x7ffffff1) vals[0] = 1ull; return; }
                 // every round probes all four entries (finished ones with key 0: CAS(0 -> 0) changes nothing)
                 uint32_t key[4];
                 int slot[4];
@@ -582,8 +589,8 @@ __global__ __launch_bounds__(SP_BLOCK, 6) void item_sparse_topk_kernel(ItemItemP
                 }
             });
             __syncthreads();
-            if (p.dbg == 102) { ca = cb; continue; }
-            if (p.dbg == 103) {
+            if (SP_DEV && p.dbg == 102) { ca = cb; continue; }
+            if (SP_DEV && p.dbg == 103) {
                 for (int v = 0; v < SP_SPT; ++v) { keys[tid + v * SP_BLOCK] = 0u; vals[tid + v * SP_BLOCK] = 0ull; }
                 ca = cb;
                 continue;
@@ -636,7 +643,7 @@ __global__ __launch_bounds__(SP_BLOCK, 6) void item_sparse_topk_kernel(ItemItemP
                 kreg[v] = sp_key(s, col);
             }
         }
-        if (p.dbg == 104) {
+        if (SP_DEV && p.dbg == 104) {
             if (dense) { __syncthreads(); if (tid < 2 * (SP_CHUNK / 32)) tbm[tid] = 0u; }
             unsigned long long z = 0;
             for (int v = 0; v < SP_REG; ++v) z ^= kreg[v];
@@ -679,7 +686,7 @@ __global__ __launch_bounds__(SP_BLOCK, 6) void item_sparse_topk_kernel(ItemItemP
         ca = cb;
     }
     __syncthreads();
-    if (p.dbg >= 101) return;
+    if (SP_DEV && p.dbg >= 101) return;
 
     // ---- untouched columns (score 0 * col_scale): only when they can still enter the list
     {

@@ -94,6 +94,8 @@ class HipScorer:
         with the user index and raises IndexError beyond them; the kernels only clamp.  The check of a device tensor
         costs one small reduction + sync, skipped when the same tensor (storage, length, version) was checked last."""
         torch = _torch()
+        if self.n_users <= 0:                     # no user side set: the library reports the missing state itself
+            return self._dev_i32(x)
         if isinstance(x, torch.Tensor) and x.is_cuda:
             u = x.to(device=self.device, dtype=torch.int32).contiguous()
             key = (u.data_ptr(), u.numel(), getattr(x, "_version", None), self.n_users)
