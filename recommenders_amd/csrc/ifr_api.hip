@@ -95,12 +95,14 @@ struct ifr_handle_s {
     int opt_chunks = 0;          // 0 = heuristic
     int opt_target_blocks = 4096;
     int opt_share_bounds = 1;    // share per-user lower bounds between item chunks
+    int opt_tail_split = 1;      // two-region grid: the last, partial round of workgroups runs shorter item chunks
     int opt_debug = 0;           // dev-only kernel ablation mode (see TopkParams::dbg)
     int opt_csr_pass = 0;        // dev/test: entries per hash pass of the CSR top-K kernel (0 = the kernel's capacity)
     int64_t opt_catalogue = 0;   // items the dense-row consumers rank (0 = n_items; > n_items: items unknown to the model)
     // profiling
     bool prof = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_used, ev_free;
+    std::vector<std::pair<const void *, int>> slots_cache;     // fused kernel -> resident workgroups on the chip
     double prof_pairs = 0.0;
 };
 
@@ -151,30 +153,39 @@ void pick_chunks(ifr_handle h, int64_t n, int *chunk_tiles, int *n_chunks, int64
     *n_chunks = (h->n_tiles + *chunk_tiles - 1) / *chunk_tiles;
 }
 
+typedef void (*topk_fn)(ifr::TopkParams);
+
 template <int KD, int KL>
-void launch_topk(bool has_base, const ifr::TopkParams &p, int grid, hipStream_t s)
+topk_fn topk_kernel(bool has_base, bool store)
 {
-    const size_t pad = (p.dbg & 64) ? 30000 : 0;     // dev ablation: extra LDS -> one workgroup per CU
-    if (p.dense != nullptr) {                        // also writes the dense score rows (ifr_rank_topk_dense)
-        if (has_base) hipLaunchKernelGGL((ifr::score_topk_kernel<KD, KL, true, true>), dim3(grid), dim3(ifr::BLOCK), pad, s, p);
-        else hipLaunchKernelGGL((ifr::score_topk_kernel<KD, KL, false, true>), dim3(grid), dim3(ifr::BLOCK), pad, s, p);
-        return;
-    }
-    if (has_base) hipLaunchKernelGGL((ifr::score_topk_kernel<KD, KL, true>), dim3(grid), dim3(ifr::BLOCK), pad, s, p);
-    else hipLaunchKernelGGL((ifr::score_topk_kernel<KD, KL, false>), dim3(grid), dim3(ifr::BLOCK), pad, s, p);
+    if (store) return has_base ? ifr::score_topk_kernel<KD, KL, true, true> : ifr::score_topk_kernel<KD, KL, false, true>;
+    return has_base ? ifr::score_topk_kernel<KD, KL, true> : ifr::score_topk_kernel<KD, KL, false>;
 }
 
 template <int KL>
-void launch_topk_kd(int KD, bool has_base, const ifr::TopkParams &p, int grid, hipStream_t s)
+topk_fn topk_kernel_kd(int KD, bool has_base, bool store)
 {
-    if (KD == 32) launch_topk<32, KL>(has_base, p, grid, s);
-    else if (KD == 64) launch_topk<64, KL>(has_base, p, grid, s);
-    else if (KD == 96) launch_topk<96, KL>(has_base, p, grid, s);
-    else if (KD == 128) launch_topk<128, KL>(has_base, p, grid, s);
-    else if (KD == 160) launch_topk<160, KL>(has_base, p, grid, s);
-    else if (KD == 192) launch_topk<192, KL>(has_base, p, grid, s);
-    else if (KD == 224) launch_topk<224, KL>(has_base, p, grid, s);
-    else launch_topk<256, KL>(has_base, p, grid, s);
+    if (KD == 32) return topk_kernel<32, KL>(has_base, store);
+    if (KD == 64) return topk_kernel<64, KL>(has_base, store);
+    if (KD == 96) return topk_kernel<96, KL>(has_base, store);
+    if (KD == 128) return topk_kernel<128, KL>(has_base, store);
+    if (KD == 160) return topk_kernel<160, KL>(has_base, store);
+    if (KD == 192) return topk_kernel<192, KL>(has_base, store);
+    if (KD == 224) return topk_kernel<224, KL>(has_base, store);
+    return topk_kernel<256, KL>(has_base, store);
+}
+
+// workgroups of `fn` that are resident on the whole chip at once (occupancy API x CUs; cached per kernel)
+int resident_slots(ifr_handle h, topk_fn fn, size_t dyn_lds)
+{
+    const void *key = reinterpret_cast<const void *>(fn);
+    for (auto &e : h->slots_cache)
+        if (e.first == key) return e.second;
+    int per_cu = 0, cus = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, key, ifr::BLOCK, dyn_lds) != hipSuccess || per_cu < 1) per_cu = 1;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device) != hipSuccess || cus < 1) cus = 256;
+    h->slots_cache.push_back({key, per_cu * cus});
+    return per_cu * cus;
 }
 
 template <int KD>
@@ -296,6 +307,7 @@ int ifr_set_option(ifr_handle h, const char *name, int64_t value)
     if (!h || !name) return IFR_ERR_ARG;
     if (!strcmp(name, "chunks")) h->opt_chunks = (int)value;
     else if (!strcmp(name, "share_bounds")) h->opt_share_bounds = (int)value;
+    else if (!strcmp(name, "tail_split")) h->opt_tail_split = (int)value;
     else if (!strcmp(name, "debug_mode")) h->opt_debug = (int)value;
     else if (!strcmp(name, "csr_pass_entries")) h->opt_csr_pass = (int)std::max<int64_t>(0, std::min<int64_t>(value, ifr::item_sparse_pass_capacity()));
     else if (!strcmp(name, "catalogue_items")) {
@@ -730,9 +742,9 @@ static int rank_topk_item_item(ifr_handle h, const int32_t *user_ids, int64_t n,
     const size_t smem = (size_t)p.n_chunks * KL * 8;
     if (smem > 60000) return fail(h, IFR_ERR_ARG, "ifr_rank_topk: catalogue too large for the merge kernel");
     if (KL == 16)
-        ifr::launch_merge_topk<16>(p.part_scores, p.part_ids, n, p.n_chunks, K, out_ids, out_scores, s);
+        ifr::launch_merge_topk<16>(p.part_scores, p.part_ids, n, p.n_chunks, p.n_chunks, K, out_ids, out_scores, s);
     else
-        ifr::launch_merge_topk<32>(p.part_scores, p.part_ids, n, p.n_chunks, K, out_ids, out_scores, s);
+        ifr::launch_merge_topk<32>(p.part_scores, p.part_ids, n, p.n_chunks, p.n_chunks, K, out_ids, out_scores, s);
     IFR_HIP(h, hipGetLastError());
     return IFR_OK;
 }
@@ -785,9 +797,38 @@ static int rank_topk_factor(ifr_handle h, const int32_t *user_ids, int64_t n, in
     }
     int chunk_tiles, n_chunks;
     pick_chunks(h, n, &chunk_tiles, &n_chunks, cap_chunks);
-    const int64_t grid = n_ut * n_chunks;
-    if (grid > (int64_t)0xffffffffu / ifr::BLOCK) return fail(h, IFR_ERR_ARG, "ifr_rank_topk: batch too large, split the user list");
-    const size_t entries = (size_t)n * n_chunks * 2 * KL;
+    const bool store = dense != nullptr;
+    const size_t dyn_lds = (h->opt_debug & 64) ? 30000 : 0;     // dev ablation: extra LDS -> one workgroup per CU
+    const topk_fn fn = KL == 16 ? topk_kernel_kd<16>(h->KD, h->has_base, store) : topk_kernel_kd<32>(h->KD, h->has_base, store);
+    // Tail balancing: with W = n_ut * n_chunks equal workgroups on S resident slots the last of ceil(W / S) rounds
+    // keeps only (W mod S) slots busy for a whole workgroup's time.  Region A = the user tiles that fill whole
+    // rounds; the rest (region B) is cut into more, shorter item chunks that fill ONE round together.
+    int n_utA = (int)n_ut, chunk_tilesB = chunk_tiles, n_chunksB = n_chunks;
+    if (h->opt_tail_split && h->opt_chunks <= 0) {
+        const int64_t S = resident_slots(h, fn, dyn_lds);
+        const int64_t W = n_ut * n_chunks, R = W / S, f = W - R * S;
+        if (R >= 1 && f > 0 && 4 * f < 3 * S) {
+            const int64_t a = R * S / n_chunks, b = n_ut - a;                    // user tiles of regions A and B
+            const int64_t max_c = std::max<int64_t>(1, std::min<int64_t>(64, h->n_tiles / 16));
+            int64_t cB = std::min(max_c, S / std::max<int64_t>(b, 1));
+            if (b > 0 && a > 0 && cB > n_chunks) {
+                n_utA = (int)a;
+                chunk_tilesB = (int)((h->n_tiles + cB - 1) / cB);
+                n_chunksB = (h->n_tiles + chunk_tilesB - 1) / chunk_tilesB;
+            }
+        }
+    }
+    // users of region A / B and their partial-list entries (2 lists of KL entries per user and item chunk)
+    int64_t nA = std::min<int64_t>(n, (int64_t)n_utA * ifr::USERS_PER_BLOCK), nB = n - nA;
+    size_t entries = ((size_t)nA * n_chunks + (size_t)nB * n_chunksB) * 2 * KL;
+    if (fixed_ws && entries * 8 + lb_bytes > fixed_bytes) {        // the static workspace only holds the one-region plan
+        n_utA = (int)n_ut; chunk_tilesB = chunk_tiles; n_chunksB = n_chunks;
+        nA = n; nB = 0;
+        entries = (size_t)n * n_chunks * 2 * KL;
+    }
+    const int max_chunks = std::max(n_chunks, n_chunksB);
+    const int64_t gridA = (int64_t)n_utA * n_chunks, grid = gridA + (n_ut - n_utA) * n_chunksB;
+    if (grid > (int64_t)0x7fffffff / ifr::BLOCK) return fail(h, IFR_ERR_ARG, "ifr_rank_topk: batch too large, split the user list");
     void *ws = fixed_ws;
     if (!ws) {
         int rc = grow(h, &h->ws_part, &h->ws_part_bytes, entries * 8 + lb_bytes);
@@ -798,6 +839,8 @@ static int rank_topk_factor(ifr_handle h, const int32_t *user_ids, int64_t n, in
     p.U = h->U; p.V = h->V; p.ibase = h->ibase; p.ubase = h->ubase;
     p.user_ids = user_ids; p.n_users = h->n_users; p.n = n; p.n_items = (int)h->n_items; p.n_tiles = h->n_tiles;
     p.chunk_tiles = chunk_tiles; p.n_chunks = n_chunks; p.K = K;
+    p.n_utA = n_utA; p.gridA = (int)gridA; p.chunk_tilesB = chunk_tilesB; p.n_chunksB = n_chunksB;
+    p.part_offB = (int64_t)nA * n_chunks * 2 * KL;
     p.ex_ptr = h->ex_ptr; p.ex_cnt = h->ex_cnt; p.ex_pair = h->ex_pair; p.ex_rows = h->ex_rows;
     p.dbg = h->opt_debug;
     p.dense = dense; p.dense_ld = dense_ld;
@@ -821,20 +864,27 @@ static int rank_topk_factor(ifr_handle h, const int32_t *user_ids, int64_t n, in
         else { IFR_HIP(h, hipEventCreate(&ev.first)); IFR_HIP(h, hipEventCreate(&ev.second)); }
         IFR_HIP(h, hipEventRecord(ev.first, s));
     }
-    if (KL == 16) launch_topk_kd<16>(h->KD, h->has_base, p, (int)grid, s);
-    else launch_topk_kd<32>(h->KD, h->has_base, p, (int)grid, s);
+    {
+        void *args[] = {&p};
+        IFR_HIP(h, hipLaunchKernel(reinterpret_cast<const void *>(fn), dim3((unsigned)grid), dim3(ifr::BLOCK), args, dyn_lds, s));
+    }
     if (prof) {
         IFR_HIP(h, hipEventRecord(ev.second, s));
         h->ev_used.push_back(ev);
         h->prof_pairs += (double)n * (double)h->n_items;
     }
     IFR_HIP(h, hipGetLastError());
-    const size_t smem = (size_t)n_chunks * 2 * KL * 8;
+    const size_t smem = (size_t)max_chunks * 2 * KL * 8;
     if (smem > 60000) return fail(h, IFR_ERR_ARG, "ifr_rank_topk: too many item chunks for the merge kernel");
-    if (KL == 16)
-        ifr::launch_merge_topk<16>(p.part_scores, p.part_ids, n, n_chunks * 2, K, out_ids, out_scores, s);
-    else
-        ifr::launch_merge_topk<32>(p.part_scores, p.part_ids, n, n_chunks * 2, K, out_ids, out_scores, s);
+    // one merge per region: a user of region A holds 2 * n_chunks lists, one of region B 2 * n_chunksB
+    const int64_t offB = p.part_offB;
+    if (KL == 16) {
+        ifr::launch_merge_topk<16>(p.part_scores, p.part_ids, nA, n_chunks * 2, n_chunks * 2, K, out_ids, out_scores, s);
+        ifr::launch_merge_topk<16>(p.part_scores + offB, p.part_ids + offB, nB, n_chunksB * 2, n_chunksB * 2, K, out_ids + nA * K, out_scores + nA * K, s);
+    } else {
+        ifr::launch_merge_topk<32>(p.part_scores, p.part_ids, nA, n_chunks * 2, n_chunks * 2, K, out_ids, out_scores, s);
+        ifr::launch_merge_topk<32>(p.part_scores + offB, p.part_ids + offB, nB, n_chunksB * 2, n_chunksB * 2, K, out_ids + nA * K, out_scores + nA * K, s);
+    }
     IFR_HIP(h, hipGetLastError());
     return IFR_OK;
 }

@@ -40,6 +40,14 @@ struct TopkParams {
     int n_tiles;             // ceil(n_items / 32)
     int chunk_tiles;         // tiles per item chunk
     int n_chunks;
+    // Two-region grid (tail balancing): user tiles [0, n_utA) run n_chunks item chunks each, in whole rounds of the
+    // resident workgroup slots; the remaining user tiles run n_chunksB >= n_chunks shorter chunks, sized so that
+    // they fill ONE last round -- instead of a last round of full-length workgroups on a fraction of the CUs.
+    // Workgroups [0, gridA) belong to region A.  One region: n_utA = all user tiles, gridA = the whole grid.
+    int n_utA, gridA;
+    int chunk_tilesB, n_chunksB;
+    int64_t part_offB;       // first entry of region B's partial lists in part_scores / part_ids (region A: 2 * n_chunks
+                             // lists of KL entries per user from entry 0; region B: 2 * n_chunksB lists per user from here)
     int K;                   // requested list length (<= KL)
     const int64_t *ex_ptr;   // may be null
     const int32_t *ex_cnt;
@@ -131,10 +139,24 @@ __global__ __launch_bounds__(BLOCK, KD > 128 ? 1 : 2) void score_topk_kernel(Top
     const int lane = tid & 63, wave = tid >> 6;
     const int j = lane & 31, h = lane >> 5;
     const int n_ut = (int)((p.n + USERS_PER_BLOCK - 1) / USERS_PER_BLOCK);
-    const int chunk = blockIdx.x / n_ut;
-    const int ut = blockIdx.x - chunk * n_ut;
-    const int t0 = chunk * p.chunk_tiles;
-    const int t1 = min(t0 + p.chunk_tiles, p.n_tiles);
+    int chunk, ut, chunk_tiles, lists;
+    int64_t part_off = 0, slot0 = 0;
+    if ((int)blockIdx.x < p.gridA) {
+        chunk = blockIdx.x / p.n_utA;
+        ut = blockIdx.x - chunk * p.n_utA;
+        chunk_tiles = p.chunk_tiles;
+        lists = 2 * p.n_chunks;
+    } else {
+        const int b = blockIdx.x - p.gridA, n_utB = n_ut - p.n_utA;
+        chunk = b / n_utB;
+        ut = p.n_utA + (b - chunk * n_utB);
+        chunk_tiles = p.chunk_tilesB;
+        lists = 2 * p.n_chunksB;
+        part_off = p.part_offB;
+        slot0 = (int64_t)p.n_utA * USERS_PER_BLOCK;
+    }
+    const int t0 = chunk * chunk_tiles;
+    const int t1 = min(t0 + chunk_tiles, p.n_tiles);
 
     const int64_t slot = (int64_t)ut * USERS_PER_BLOCK + wave * 32 + j;
     const bool live = slot < p.n;
@@ -363,7 +385,7 @@ __global__ __launch_bounds__(BLOCK, KD > 128 ? 1 : 2) void score_topk_kernel(Top
     // ---- final drain and write the lane's partial list
     flush();
     if (live) {
-        const int64_t base = ((slot * p.n_chunks + chunk) * 2 + h) * KL;
+        const int64_t base = part_off + ((slot - slot0) * lists + chunk * 2 + h) * KL;
 #pragma unroll
         for (int i = 0; i < KL; ++i) { p.part_scores[base + i] = ls[i]; p.part_ids[base + i] = li[i]; }
     }
@@ -381,7 +403,7 @@ __device__ __forceinline__ bool beats(float s, int id, float s2, int id2)
 
 template <int KL>
 __global__ __launch_bounds__(64) void merge_topk_kernel(const float *part_scores, const int32_t *part_ids,
-                                                        int64_t n, int n_lists, int K,
+                                                        int64_t n, int n_lists, int stride_lists, int K,
                                                         int32_t *out_ids, float *out_scores)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -390,8 +412,8 @@ __global__ __launch_bounds__(64) void merge_topk_kernel(const float *part_scores
     const int64_t u = blockIdx.x;
     const int lane = threadIdx.x;
     const int E = n_lists * KL;
-    const float *ps = part_scores + u * E;
-    const int32_t *pi = part_ids + u * E;
+    const float *ps = part_scores + u * (int64_t)stride_lists * KL;
+    const int32_t *pi = part_ids + u * (int64_t)stride_lists * KL;
     for (int e = lane; e < E; e += 64) { es[e] = ps[e]; ei[e] = pi[e]; }
     __syncthreads();
     int n_valid = 0;
@@ -429,7 +451,7 @@ constexpr int MERGE_WAVES = 4;
 
 template <int KL, int NE>
 __global__ __launch_bounds__(64 * MERGE_WAVES) void merge_pairs_kernel(const float *part_scores, const int32_t *part_ids,
-                                                                       int64_t n, int n_lists, int K,
+                                                                       int64_t n, int n_lists, int stride_lists, int K,
                                                                        int32_t *out_ids, float *out_scores)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -439,8 +461,8 @@ __global__ __launch_bounds__(64 * MERGE_WAVES) void merge_pairs_kernel(const flo
     const int Epad = (E + 7) & ~7;
     unsigned long long *keys = reinterpret_cast<unsigned long long *>(smem) + (size_t)w * Epad;
     const bool live = u < n;
-    const float *ps = part_scores + (live ? u : 0) * (int64_t)n_lists * KL;
-    const int32_t *pi = part_ids + (live ? u : 0) * (int64_t)n_lists * KL;
+    const float *ps = part_scores + (live ? u : 0) * (int64_t)stride_lists * KL;
+    const int32_t *pi = part_ids + (live ? u : 0) * (int64_t)stride_lists * KL;
     unsigned long long k[NE];
     float sc[NE];
     int n_valid = 0;
@@ -482,22 +504,24 @@ __global__ __launch_bounds__(64 * MERGE_WAVES) void merge_pairs_kernel(const flo
     for (int r = n_valid + lane; r < K; r += 64) { out_ids[u * K + r] = -1; out_scores[u * K + r] = -INFINITY; }
 }
 
+// stride_lists: partial lists between two users' blocks in part_scores / part_ids (>= n_lists, the lists that are read)
 template <int KL>
-inline void launch_merge_topk(const float *part_scores, const int32_t *part_ids, int64_t n, int n_lists, int K,
+inline void launch_merge_topk(const float *part_scores, const int32_t *part_ids, int64_t n, int n_lists, int stride_lists, int K,
                               int32_t *out_ids, float *out_scores, hipStream_t s)
 {
+    if (n <= 0) return;
     const int E = n_lists * K;
     const unsigned grid4 = (unsigned)((n + MERGE_WAVES - 1) / MERGE_WAVES);
     const size_t smem4 = (size_t)MERGE_WAVES * ((E + 7) & ~7) * 8;
     if (E <= 64)
-        hipLaunchKernelGGL((merge_pairs_kernel<KL, 1>), dim3(grid4), dim3(64 * MERGE_WAVES), smem4, s, part_scores, part_ids, n, n_lists, K, out_ids, out_scores);
+        hipLaunchKernelGGL((merge_pairs_kernel<KL, 1>), dim3(grid4), dim3(64 * MERGE_WAVES), smem4, s, part_scores, part_ids, n, n_lists, stride_lists, K, out_ids, out_scores);
     else if (E <= 128)
-        hipLaunchKernelGGL((merge_pairs_kernel<KL, 2>), dim3(grid4), dim3(64 * MERGE_WAVES), smem4, s, part_scores, part_ids, n, n_lists, K, out_ids, out_scores);
+        hipLaunchKernelGGL((merge_pairs_kernel<KL, 2>), dim3(grid4), dim3(64 * MERGE_WAVES), smem4, s, part_scores, part_ids, n, n_lists, stride_lists, K, out_ids, out_scores);
     else if (E <= 256)
-        hipLaunchKernelGGL((merge_pairs_kernel<KL, 4>), dim3(grid4), dim3(64 * MERGE_WAVES), smem4, s, part_scores, part_ids, n, n_lists, K, out_ids, out_scores);
+        hipLaunchKernelGGL((merge_pairs_kernel<KL, 4>), dim3(grid4), dim3(64 * MERGE_WAVES), smem4, s, part_scores, part_ids, n, n_lists, stride_lists, K, out_ids, out_scores);
     else
         hipLaunchKernelGGL((merge_topk_kernel<KL>), dim3((unsigned)n), dim3(64), (size_t)n_lists * KL * 8, s, part_scores, part_ids, n,
-                           n_lists, K, out_ids, out_scores);
+                           n_lists, stride_lists, K, out_ids, out_scores);
 }
 
 // ------------------------------------------------------------------------------------
