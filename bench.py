@@ -182,6 +182,8 @@ def build_workload(config, args, rank, dev):
         sc.set_option("debug_mode", dbg)
     if os.environ.get("IFR_CHUNKS"):
         sc.set_option("chunks", int(os.environ["IFR_CHUNKS"]))
+    if os.environ.get("IFR_WIDE_CHUNK_CAP"):
+        sc.set_option("wide_chunk_cap", int(os.environ["IFR_WIDE_CHUNK_CAP"]))
     if config in synth.ITEM_CONFIGS:
         w = synth.make_item(config, n_users=args.users, n_items=args.items,
                             seed=synth.ITEM_CONFIGS[config][3] + 1000 * rank, device=dev)
@@ -325,12 +327,19 @@ def run_config(config, args, steps, warmup, world, rank, dev, D, with_cpu, auc=F
         "data": "synthetic",
         "config": cfg,
         "roofline": roof,
-        "variant": "top-10 + NDCG/Recall/Precision@10" + ((" + AUC (score rows written by the fused kernel)" if auc_fused else " + AUC (dense rows)") if auc else ""),
-        "eval": {"ndcg@10": sums[0] / sums[-1], "recall@10": sums[1] / sums[-1],
-                 "precision@10": sums[2] / sums[-1], "n_evaluated": float(sums[-1])},
+        "variant": f"top-{TOPK} + NDCG/Recall/Precision@{TOPK}" + ((" + AUC (score rows written by the fused kernel)" if auc_fused else " + AUC (dense rows)") if auc else ""),
+        "eval": {f"ndcg@{TOPK}": sums[0] / sums[-1], f"recall@{TOPK}": sums[1] / sums[-1],
+                 f"precision@{TOPK}": sums[2] / sums[-1], "n_evaluated": float(sums[-1])},
     }
     if auc:
         out["eval"]["auc"] = float(torch.nanmean(auc_out).item())
+    if not item_model and TOPK > 16:
+        sc.set_option("wide_stats", 1)             # one more, untimed pass that counts the candidates
+        step()
+        torch.cuda.synchronize(dev)
+        wu, wc, wk = sc.wide_stats()
+        out["wide_path"] = {"overflow_users": sc.wide_overflows(), "users": wu, "candidates_per_user": wc / max(wu, 1),
+                            "kept_per_user": wk / max(wu, 1)}
     if with_cpu:
         m = min(args.cpu_sample_of(config), n, w.get("host_rows", n))
         if item_model:
@@ -341,7 +350,7 @@ def run_config(config, args, steps, warmup, world, rank, dev, D, with_cpu, auc=F
             if config == "c2_wmf_ml20m":
                 out["cpu_baseline_strong"] = cpu_strong(w, min(2048, n))
         out["cpu_baseline"] = base
-        out["parity_on_cpu_sample"] = {"users": m, "top10_ids_equal": bool((h_ids2[(step_no[0] - 1) & 1][:m].numpy() == o_ids).all())}
+        out["parity_on_cpu_sample"] = {"users": m, "top10_ids_equal" if TOPK == 10 else f"top{TOPK}_ids_equal": bool((h_ids2[(step_no[0] - 1) & 1][:m].numpy() == o_ids).all())}
     sc.close()
     return out
 
@@ -358,8 +367,11 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="headline only")
     ap.add_argument("--host-synth", action="store_true", help="c3_mf_shard: NumPy generator (Zipf items) instead of the device one")
+    ap.add_argument("--topk", type=int, default=10, help="list length K (default 10, the metric's; 17..128 takes the candidate-buffer variant of the fused kernel)")
     ap.add_argument("--auc", action="store_true", help="second variant of SURVEY.md 8d: also AUC (dense score rows + ifr_auc_dense)")
     args = ap.parse_args()
+    global TOPK
+    TOPK = args.topk
 
     import torch
     import torch.distributed as dist

@@ -38,7 +38,8 @@ enum {
 };
 
 #define IFR_MAX_FACTORS 256  /* latent dimension k supported by the fused kernel   */
-#define IFR_MAX_TOPK 32      /* K supported by the fused score+select kernel       */
+#define IFR_MAX_TOPK 128     /* K supported by the fused score+select kernel (dot-product models) */
+#define IFR_MAX_TOPK_ITEM 32 /* ... for item-item models                                          */
 
 /* Library / handle life cycle.  (No reference counterpart: the reference keeps model
  * parameters as NumPy arrays on the Recommender object, cornac/models/recommender.py:160-168.) */
@@ -138,7 +139,14 @@ int ifr_set_truth_csr(ifr_handle h, const int64_t *indptr, const int32_t *indice
  * Recommender.rank (cornac/models/recommender.py:624-652: score, candidate gather,
  * argsort/argpartition) for every listed user at once.  Order: score descending, item index
  * ascending on ties.  out_ids/out_scores: dev [n][K]; unfilled slots (fewer than K
- * candidates) hold id -1 / score -inf.  1 <= K <= IFR_MAX_TOPK.  user_ids: dev [n]. */
+ * candidates) hold id -1 / score -inf.  user_ids: dev [n].
+ * 1 <= K <= IFR_MAX_TOPK for dot-product models, IFR_MAX_TOPK_ITEM for item-item models.  K <= 16: lane-private
+ * sorted lists, merged per user; the call is asynchronous on `stream`.  16 < K <= 128 (dot-product models): the lists
+ * only supply a lower bound of the user's K-th best score, every score that reaches it goes to a per-user candidate
+ * buffer (16 K entries, at least 512) and the exact top K is selected from it -- the score matrix still never reaches
+ * HBM (Recall@50 / @100, re-ranker pools: recommender.py:644-649, rerankers/reranker.py:620-639).  A user whose buffer
+ * overflows (scores that rise with the item index) is ranked from a dense score row instead; to find those users the
+ * call synchronises `stream` once before it returns. */
 int ifr_rank_topk(ifr_handle h, const int32_t *user_ids, int64_t n, int K,
                   int32_t *out_ids, float *out_scores, void *stream);
 
@@ -157,13 +165,14 @@ int ifr_rank_topk_dense(ifr_handle h, const int32_t *user_ids, int64_t n, int K,
  * a dot-product model (IFR_ERR_STATE otherwise), but the call makes no hipMalloc / hipFree / allocating library call:
  * the partial top-K lists and per-user bound words live in a static __device__ array of IFR_NOALLOC_SCRATCH_BYTES that
  * every GPU the library runs on holds until the process ends (its per-device address is looked up once in ifr_create).
- * Limits: n <= IFR_NOALLOC_MAX_USERS users per call (IFR_ERR_ARG beyond; with K > 16 the lists are twice as wide and
- * the static workspace holds fewer item chunks, never fewer users); K <= IFR_MAX_TOPK; no profiling events are
+ * Limits: n <= IFR_NOALLOC_MAX_USERS users per call (IFR_ERR_ARG beyond); K <= IFR_NOALLOC_MAX_TOPK (longer lists need
+ * candidate buffers of a size that depends on the batch, and one stream synchronisation); no profiling events are
  * recorded for it.  All calls on one GPU share that GPU's array -- whatever handle they use -- and the array keeps the
  * last call's contents (the call clears what it needs at zero itself): calls that overlap on one GPU, on different
  * streams or from different handles, race.  Calls on one stream are ordered by it. */
 #define IFR_NOALLOC_SCRATCH_BYTES (64u << 20)
 #define IFR_NOALLOC_MAX_USERS 65536
+#define IFR_NOALLOC_MAX_TOPK 16
 int ifr_rank_topk_noalloc(ifr_handle h, const int32_t *user_ids, int64_t n, int K,
                           int32_t *out_ids, float *out_scores, void *stream);
 
@@ -251,10 +260,20 @@ int ifr_pad_scores_min(ifr_handle h, float *scores, int64_t n, int64_t ld, void 
 int ifr_profile_enable(ifr_handle h, int on);
 int ifr_profile_read(ifr_handle h, double *kernel_ms, int64_t *launches, double *pairs_scored);
 
+/* Users that ifr_rank_topk / ifr_rank_topk_dense (16 < K <= 128) ranked from a dense score row since the handle was
+ * created, because their candidate buffer overflowed (no reference counterpart; a health counter: the results are
+ * the same either way, the fallback is only slower). */
+int ifr_wide_overflows(ifr_handle h, int64_t *count);
+/* ... and the volume behind it: users that path ranked, candidates their buffers received, candidates that reached the
+ * final bound (the ones the exact selection ranks); users whose buffer overflowed count in `users` only. */
+int ifr_wide_stats(ifr_handle h, int64_t *users, double *candidates, double *kept);
+
 /* Development only (no reference counterpart): per-phase cycle sums of the fused kernel's main loop, written when the
  * library is built with `make STAMPS=1` and the option "debug_mode" has bit 7 set (tools/stamps.py).  out: host
  * [cap] 64-bit words, *n = words written ([grid][4 waves][8]); 0 words in a normal build. */
 int ifr_debug_read_stamps(ifr_handle h, unsigned long long *out, int64_t cap, int64_t *n);
+/* Development only: the per-user candidate counts of the handle's last 16 < K <= 128 ranking call (host out[cap]). */
+int ifr_debug_wide_counts(ifr_handle h, uint32_t *out, int64_t cap, int64_t *n);
 
 /* The k-index order of the fp32 fma chain the kernels accumulate each dot product in
  * (perm[t] = factor index consumed at chain step t, for the padded dimension the handle

@@ -50,6 +50,9 @@ SIGNATURES = {
     "ifr_pad_scores_min": (ctypes.c_int, [vp, vp, ctypes.c_int64, ctypes.c_int64, vp]),
     "ifr_profile_enable": (ctypes.c_int, [vp, ctypes.c_int]),
     "ifr_profile_read": (ctypes.c_int, [vp, c_f64p, c_i64p, c_f64p]),
+    "ifr_wide_overflows": (ctypes.c_int, [vp, c_i64p]),
+    "ifr_wide_stats": (ctypes.c_int, [vp, c_i64p, c_f64p, c_f64p]),
+    "ifr_debug_wide_counts": (ctypes.c_int, [vp, vp, ctypes.c_int64, c_i64p]),
     "ifr_debug_read_stamps": (ctypes.c_int, [vp, vp, ctypes.c_int64, c_i64p]),
     "ifr_factor_chain_order": (ctypes.c_int, [vp, c_i32p, ctypes.POINTER(ctypes.c_int)]),
 }

@@ -95,6 +95,8 @@ struct ifr_handle_s {
     int opt_chunks = 0;          // 0 = heuristic
     int opt_target_blocks = 4096;
     int opt_share_bounds = 1;    // share per-user lower bounds between item chunks
+    int opt_wide_stats = 0;      // count the candidates of the 16 < K <= 128 path (two contended atomics per user: measurement runs only)
+    int opt_wide_chunk_cap = 2;  // item chunks of that path beyond the ceil(K / 24) its bound needs (more lists loosen the bound)
     int opt_tail_split = 1;      // two-region grid: the last, partial round of workgroups runs shorter item chunks
     int opt_debug = 0;           // dev-only kernel ablation mode (see TopkParams::dbg)
     int opt_csr_pass = 0;        // dev/test: entries per hash pass of the CSR top-K kernel (0 = the kernel's capacity)
@@ -104,6 +106,10 @@ struct ifr_handle_s {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_used, ev_free;
     std::vector<std::pair<const void *, int>> slots_cache;     // fused kernel -> resident workgroups on the chip
     double prof_pairs = 0.0;
+    const uint32_t *dbg_wide_cnt = nullptr; int64_t dbg_wide_n = 0;     // dev: candidate counts of the last 16 < K <= 128 call
+    int64_t wide_users = 0;      // ... users that path ranked, candidates it appended / kept after the final bound
+    double wide_cand = 0.0, wide_kept = 0.0;
+    int64_t wide_overflows = 0;  // users of the 16 < K <= 128 path ranked from dense rows because their candidate buffer overflowed
 };
 
 namespace {
@@ -155,24 +161,28 @@ void pick_chunks(ifr_handle h, int64_t n, int *chunk_tiles, int *n_chunks, int64
 
 typedef void (*topk_fn)(ifr::TopkParams);
 
-template <int KD, int KL>
-topk_fn topk_kernel(bool has_base, bool store)
+// the fused kernel's instantiation: lane lists of 16 entries (K <= 16 exact; WIDE: 16 < K <= 128 through candidate buffers)
+template <int KD>
+topk_fn topk_kernel(bool has_base, bool store, bool wide)
 {
-    if (store) return has_base ? ifr::score_topk_kernel<KD, KL, true, true> : ifr::score_topk_kernel<KD, KL, false, true>;
-    return has_base ? ifr::score_topk_kernel<KD, KL, true> : ifr::score_topk_kernel<KD, KL, false>;
+    if (wide) {
+        if (store) return has_base ? ifr::score_topk_kernel<KD, 16, true, true, true> : ifr::score_topk_kernel<KD, 16, false, true, true>;
+        return has_base ? ifr::score_topk_kernel<KD, 16, true, false, true> : ifr::score_topk_kernel<KD, 16, false, false, true>;
+    }
+    if (store) return has_base ? ifr::score_topk_kernel<KD, 16, true, true> : ifr::score_topk_kernel<KD, 16, false, true>;
+    return has_base ? ifr::score_topk_kernel<KD, 16, true> : ifr::score_topk_kernel<KD, 16, false>;
 }
 
-template <int KL>
-topk_fn topk_kernel_kd(int KD, bool has_base, bool store)
+topk_fn topk_kernel_kd(int KD, bool has_base, bool store, bool wide)
 {
-    if (KD == 32) return topk_kernel<32, KL>(has_base, store);
-    if (KD == 64) return topk_kernel<64, KL>(has_base, store);
-    if (KD == 96) return topk_kernel<96, KL>(has_base, store);
-    if (KD == 128) return topk_kernel<128, KL>(has_base, store);
-    if (KD == 160) return topk_kernel<160, KL>(has_base, store);
-    if (KD == 192) return topk_kernel<192, KL>(has_base, store);
-    if (KD == 224) return topk_kernel<224, KL>(has_base, store);
-    return topk_kernel<256, KL>(has_base, store);
+    if (KD == 32) return topk_kernel<32>(has_base, store, wide);
+    if (KD == 64) return topk_kernel<64>(has_base, store, wide);
+    if (KD == 96) return topk_kernel<96>(has_base, store, wide);
+    if (KD == 128) return topk_kernel<128>(has_base, store, wide);
+    if (KD == 160) return topk_kernel<160>(has_base, store, wide);
+    if (KD == 192) return topk_kernel<192>(has_base, store, wide);
+    if (KD == 224) return topk_kernel<224>(has_base, store, wide);
+    return topk_kernel<256>(has_base, store, wide);
 }
 
 // workgroups of `fn` that are resident on the whole chip at once (occupancy API x CUs; cached per kernel)
@@ -308,6 +318,8 @@ int ifr_set_option(ifr_handle h, const char *name, int64_t value)
     if (!strcmp(name, "chunks")) h->opt_chunks = (int)value;
     else if (!strcmp(name, "share_bounds")) h->opt_share_bounds = (int)value;
     else if (!strcmp(name, "tail_split")) h->opt_tail_split = (int)value;
+    else if (!strcmp(name, "wide_stats")) h->opt_wide_stats = (int)value;
+    else if (!strcmp(name, "wide_chunk_cap")) h->opt_wide_chunk_cap = (int)std::max<int64_t>(1, value);
     else if (!strcmp(name, "debug_mode")) h->opt_debug = (int)value;
     else if (!strcmp(name, "csr_pass_entries")) h->opt_csr_pass = (int)std::max<int64_t>(0, std::min<int64_t>(value, ifr::item_sparse_pass_capacity()));
     else if (!strcmp(name, "catalogue_items")) {
@@ -753,6 +765,9 @@ static int rank_topk_item_item(ifr_handle h, const int32_t *user_ids, int64_t n,
 // fixed_ws != nullptr: the workspace is that buffer of fixed_bytes (nothing is allocated, no profiling events)
 static int rank_topk_factor(ifr_handle h, const int32_t *user_ids, int64_t n, int K, int KL, int32_t *out_ids, float *out_scores,
                             float *dense, int64_t dense_ld, hipStream_t s, void *fixed_ws = nullptr, size_t fixed_bytes = 0);
+// the same for 16 < K <= 128 (candidate buffers + exact selection; synchronises the stream once to look for overflows)
+static int rank_topk_wide(ifr_handle h, const int32_t *user_ids, int64_t n, int K, int32_t *out_ids, float *out_scores,
+                          float *dense, int64_t dense_ld, hipStream_t s);
 
 int ifr_rank_topk(ifr_handle h, const int32_t *user_ids, int64_t n, int K, int32_t *out_ids, float *out_scores, void *stream)
 {
@@ -760,12 +775,15 @@ int ifr_rank_topk(ifr_handle h, const int32_t *user_ids, int64_t n, int K, int32
     if (h->mode == MODE_NONE) return fail(h, IFR_ERR_STATE, "ifr_rank_topk: no model set");
     if (n == 0) return IFR_OK;
     if (!user_ids || !out_ids || !out_scores || n < 0) return fail(h, IFR_ERR_ARG, "ifr_rank_topk: null/negative argument");
-    if (K < 1 || K > IFR_MAX_TOPK) return fail(h, IFR_ERR_ARG, "ifr_rank_topk: K must be in [1, 32]");
+    if (K < 1 || K > IFR_MAX_TOPK) return fail(h, IFR_ERR_ARG, "ifr_rank_topk: K must be in [1, 128]");
     IFR_HIP(h, hipSetDevice(h->device));
     hipStream_t s = (hipStream_t)stream;
-    const int KL = K <= 16 ? 16 : 32;
-    if (h->mode != MODE_FACTOR) return rank_topk_item_item(h, user_ids, n, K, KL, out_ids, out_scores, s);
-    return rank_topk_factor(h, user_ids, n, K, KL, out_ids, out_scores, nullptr, 0, s);
+    if (h->mode != MODE_FACTOR) {
+        if (K > IFR_MAX_TOPK_ITEM) return fail(h, IFR_ERR_ARG, "ifr_rank_topk: item-item models: K must be in [1, 32] (larger cut-offs: ifr_score_dense + ifr_select_topk)");
+        return rank_topk_item_item(h, user_ids, n, K, K <= 16 ? 16 : 32, out_ids, out_scores, s);
+    }
+    if (K > 16) return rank_topk_wide(h, user_ids, n, K, out_ids, out_scores, nullptr, 0, s);
+    return rank_topk_factor(h, user_ids, n, K, 16, out_ids, out_scores, nullptr, 0, s);
 }
 
 int ifr_rank_topk_dense(ifr_handle h, const int32_t *user_ids, int64_t n, int K, int32_t *out_ids, float *out_scores,
@@ -776,11 +794,12 @@ int ifr_rank_topk_dense(ifr_handle h, const int32_t *user_ids, int64_t n, int K,
         return fail(h, IFR_ERR_STATE, "ifr_rank_topk_dense: needs a dot-product model (ifr_set_factors); use ifr_rank_topk + ifr_score_dense");
     if (n == 0) return IFR_OK;
     if (!user_ids || !out_ids || !out_scores || !dense_out || n < 0) return fail(h, IFR_ERR_ARG, "ifr_rank_topk_dense: null/negative argument");
-    if (K < 1 || K > IFR_MAX_TOPK) return fail(h, IFR_ERR_ARG, "ifr_rank_topk_dense: K must be in [1, 32]");
+    if (K < 1 || K > IFR_MAX_TOPK) return fail(h, IFR_ERR_ARG, "ifr_rank_topk_dense: K must be in [1, 128]");
     if (ld < (int64_t)h->n_tiles * ifr::TILE_I || (ld & 3) || ((uintptr_t)dense_out & 15))
         return fail(h, IFR_ERR_ARG, "ifr_rank_topk_dense: ld must be a multiple of 4 and >= n_items rounded up to 32, dense_out 16-byte aligned");
     IFR_HIP(h, hipSetDevice(h->device));
-    return rank_topk_factor(h, user_ids, n, K, K <= 16 ? 16 : 32, out_ids, out_scores, dense_out, ld, (hipStream_t)stream);
+    if (K > 16) return rank_topk_wide(h, user_ids, n, K, out_ids, out_scores, dense_out, ld, (hipStream_t)stream);
+    return rank_topk_factor(h, user_ids, n, K, 16, out_ids, out_scores, dense_out, ld, (hipStream_t)stream);
 }
 
 static int rank_topk_factor(ifr_handle h, const int32_t *user_ids, int64_t n, int K, int KL, int32_t *out_ids, float *out_scores,
@@ -799,7 +818,7 @@ static int rank_topk_factor(ifr_handle h, const int32_t *user_ids, int64_t n, in
     pick_chunks(h, n, &chunk_tiles, &n_chunks, cap_chunks);
     const bool store = dense != nullptr;
     const size_t dyn_lds = (h->opt_debug & 64) ? 30000 : 0;     // dev ablation: extra LDS -> one workgroup per CU
-    const topk_fn fn = KL == 16 ? topk_kernel_kd<16>(h->KD, h->has_base, store) : topk_kernel_kd<32>(h->KD, h->has_base, store);
+    const topk_fn fn = topk_kernel_kd(h->KD, h->has_base, store, false);
     // Tail balancing: with W = n_ut * n_chunks equal workgroups on S resident slots the last of ceil(W / S) rounds
     // keeps only (W mod S) slots busy for a whole workgroup's time.  Region A = the user tiles that fill whole
     // rounds; the rest (region B) is cut into more, shorter item chunks that fill ONE round together.
@@ -844,6 +863,7 @@ static int rank_topk_factor(ifr_handle h, const int32_t *user_ids, int64_t n, in
     p.ex_ptr = h->ex_ptr; p.ex_cnt = h->ex_cnt; p.ex_pair = h->ex_pair; p.ex_rows = h->ex_rows;
     p.dbg = h->opt_debug;
     p.dense = dense; p.dense_ld = dense_ld;
+    p.lbm = nullptr; p.bw = nullptr; p.started = nullptr; p.wide_lists = 0; p.m_rank = 0; p.cand = nullptr; p.cand_cnt = nullptr; p.cand_cap = 0;
     p.stamps = nullptr;
     if ((h->opt_debug & 128) && !fixed_ws) {        // dev-only phase timing, read back by ifr_debug_read_stamps
         int rc2 = grow(h, &h->ws_met, &h->ws_met_bytes, (size_t)grid * 4 * 8 * sizeof(unsigned long long));
@@ -878,13 +898,9 @@ static int rank_topk_factor(ifr_handle h, const int32_t *user_ids, int64_t n, in
     if (smem > 60000) return fail(h, IFR_ERR_ARG, "ifr_rank_topk: too many item chunks for the merge kernel");
     // one merge per region: a user of region A holds 2 * n_chunks lists, one of region B 2 * n_chunksB
     const int64_t offB = p.part_offB;
-    if (KL == 16) {
-        ifr::launch_merge_topk<16>(p.part_scores, p.part_ids, nA, n_chunks * 2, n_chunks * 2, K, out_ids, out_scores, s);
-        ifr::launch_merge_topk<16>(p.part_scores + offB, p.part_ids + offB, nB, n_chunksB * 2, n_chunksB * 2, K, out_ids + nA * K, out_scores + nA * K, s);
-    } else {
-        ifr::launch_merge_topk<32>(p.part_scores, p.part_ids, nA, n_chunks * 2, n_chunks * 2, K, out_ids, out_scores, s);
-        ifr::launch_merge_topk<32>(p.part_scores + offB, p.part_ids + offB, nB, n_chunksB * 2, n_chunksB * 2, K, out_ids + nA * K, out_scores + nA * K, s);
-    }
+    if (KL != 16) return fail(h, IFR_ERR_ARG, "ifr_rank_topk: internal: lane lists are 16 entries");
+    ifr::launch_merge_topk<16>(p.part_scores, p.part_ids, nA, n_chunks * 2, n_chunks * 2, K, out_ids, out_scores, s);
+    ifr::launch_merge_topk<16>(p.part_scores + offB, p.part_ids + offB, nB, n_chunksB * 2, n_chunksB * 2, K, out_ids + nA * K, out_scores + nA * K, s);
     IFR_HIP(h, hipGetLastError());
     return IFR_OK;
 }
@@ -895,11 +911,112 @@ int ifr_rank_topk_noalloc(ifr_handle h, const int32_t *user_ids, int64_t n, int 
     if (h->mode != MODE_FACTOR) return fail(h, IFR_ERR_STATE, "ifr_rank_topk_noalloc: needs a dot-product model (ifr_set_factors)");
     if (n == 0) return IFR_OK;
     if (!user_ids || !out_ids || !out_scores || n < 0) return fail(h, IFR_ERR_ARG, "ifr_rank_topk_noalloc: null/negative argument");
-    if (K < 1 || K > IFR_MAX_TOPK) return fail(h, IFR_ERR_ARG, "ifr_rank_topk_noalloc: K must be in [1, 32]");
+    if (K < 1 || K > IFR_NOALLOC_MAX_TOPK) return fail(h, IFR_ERR_ARG, "ifr_rank_topk_noalloc: K must be in [1, 16]");
     if (n > IFR_NOALLOC_MAX_USERS) return fail(h, IFR_ERR_ARG, "ifr_rank_topk_noalloc: more than IFR_NOALLOC_MAX_USERS (65536) users in one call");
     IFR_HIP(h, hipSetDevice(h->device));
-    return rank_topk_factor(h, user_ids, n, K, K <= 16 ? 16 : 32, out_ids, out_scores, nullptr, 0, (hipStream_t)stream,
+    return rank_topk_factor(h, user_ids, n, K, 16, out_ids, out_scores, nullptr, 0, (hipStream_t)stream,
                             h->scratch, (size_t)IFR_NOALLOC_SCRATCH_BYTES);
+}
+
+
+static int rank_topk_wide(ifr_handle h, const int32_t *user_ids, int64_t n, int K, int32_t *out_ids, float *out_scores,
+                          float *dense, int64_t dense_ld, hipStream_t s)
+{
+    if (!h->U || !h->V || h->n_users <= 0) return fail(h, IFR_ERR_STATE, "ifr_rank_topk: no user factors set");
+    const int64_t n_ut = (n + ifr::USERS_PER_BLOCK - 1) / ifr::USERS_PER_BLOCK;
+    // item chunks: enough lists (2 per chunk) for a bound at list depth <= 12; beyond that as many as fill the chip, but
+    // chunks of at least 32 tiles: until its bound words meet (2-3 tiles) a lane appends every score it sees
+    const int64_t need_c = (K + 23) / 24;
+    const int64_t want = h->opt_chunks > 0 ? h->opt_chunks : (h->opt_target_blocks + n_ut - 1) / n_ut;
+    int64_t c = h->opt_chunks > 0 ? std::max(need_c, want) : std::max(need_c, std::min<int64_t>(want, std::min<int64_t>(h->opt_wide_chunk_cap, std::max(1, h->n_tiles / 32))));
+    c = std::max<int64_t>(1, std::min<int64_t>(c, std::min<int64_t>(ifr::WIDE_MAX_LISTS / 2, h->n_tiles)));
+    const int chunk_tiles = (int)((h->n_tiles + c - 1) / c);
+    const int n_chunks = (h->n_tiles + chunk_tiles - 1) / chunk_tiles;
+    const int L = 2 * n_chunks;
+    // candidate buffer: what a lane appends before the user's bound words meet (about 3 tiles of 16 scores per list) plus
+    // 5 x the K (1 + ln(I / K)) entries an ideal running K-th-best threshold lets through (the min-over-lists bound is
+    // looser, and late); measured at 26 744 items 1.9 x, at 1 M items 3 x the ideal count
+    const double ideal = (double)K * (1.0 + std::log(std::max(1.0, (double)h->n_items / (double)K)));
+    const int cap = (int)std::min<double>(ifr::CAND_MAX, std::max(512.0, 48.0 * L + 5.0 * ideal));
+    const int64_t grid = n_ut * n_chunks;
+    if (grid > (int64_t)0x7fffffff / ifr::BLOCK) return fail(h, IFR_ERR_ARG, "ifr_rank_topk: batch too large, split the user list");
+    // workspace: [cand n*cap*8][zeroed: cand_cnt n*4, bw n*4, lbm n*L*4, started n_ut*4, overflow count + statistics][overflow_slots n*4]
+    const size_t cand_bytes = (size_t)n * cap * 8;
+    const size_t wl_bytes = 0;
+    const size_t tail_off = ((size_t)n * 8 + (size_t)n * L * 4 + (size_t)n_ut * 4 + 7) & ~(size_t)7;      // overflow count + statistics, 8-byte aligned
+    const size_t zero_bytes = (tail_off + 24 + 255) / 256 * 256;
+    const size_t need = cand_bytes + wl_bytes + zero_bytes + (size_t)n * 4;
+    int rc = grow(h, &h->ws_part, &h->ws_part_bytes, need);
+    if (rc) return rc;
+    char *ws = (char *)h->ws_part;
+    ifr::TopkParams p;
+    memset(&p, 0, sizeof(p));
+    p.U = h->U; p.V = h->V; p.ibase = h->ibase; p.ubase = h->ubase;
+    p.user_ids = user_ids; p.n_users = h->n_users; p.n = n; p.n_items = (int)h->n_items; p.n_tiles = h->n_tiles;
+    p.chunk_tiles = chunk_tiles; p.n_chunks = n_chunks; p.K = K;
+    p.n_utA = (int)n_ut; p.gridA = (int)grid; p.chunk_tilesB = chunk_tiles; p.n_chunksB = n_chunks;
+    p.ex_ptr = h->ex_ptr; p.ex_cnt = h->ex_cnt; p.ex_pair = h->ex_pair; p.ex_rows = h->ex_rows;
+    p.dbg = h->opt_debug & 7;
+    p.dense = dense; p.dense_ld = dense_ld;
+    p.cand = (uint2 *)ws;
+    char *zr = ws + cand_bytes + wl_bytes;
+    p.cand_cnt = (uint32_t *)zr;
+    p.bw = p.cand_cnt + n;
+    p.lbm = p.bw + n;
+    p.started = p.lbm + (size_t)n * L;
+    uint32_t *overflow_cnt = (uint32_t *)(zr + tail_off);
+    unsigned long long *stats = (unsigned long long *)(zr + tail_off + 8);
+    int32_t *overflow_slots = (int32_t *)(zr + zero_bytes);
+    p.wide_lists = L; p.cand_cap = cap;
+    h->dbg_wide_cnt = p.cand_cnt; h->dbg_wide_n = n;
+    p.m_rank = (K + L - 1) / L <= 16 ? (K + L - 1) / L : 17;
+    IFR_HIP(h, hipMemsetAsync(p.cand_cnt, 0, zero_bytes, s));
+
+    const topk_fn fn = topk_kernel_kd(h->KD, h->has_base, dense != nullptr, true);
+    std::pair<hipEvent_t, hipEvent_t> ev;
+    rc = prof_begin(h, s, &ev);
+    if (rc) return rc;
+    {
+        void *args[] = {&p};
+        IFR_HIP(h, hipLaunchKernel(reinterpret_cast<const void *>(fn), dim3((unsigned)grid), dim3(ifr::BLOCK), args, 0, s));
+    }
+    rc = prof_end(h, s, ev, (double)n * (double)h->n_items);
+    if (rc) return rc;
+    ifr::CandParams cp;
+    cp.cand = p.cand; cp.cand_cnt = p.cand_cnt; cp.bw = p.bw; cp.cand_cap = cap; cp.n = n; cp.K = K;
+    cp.out_ids = out_ids; cp.out_scores = out_scores; cp.overflow_cnt = overflow_cnt; cp.stats = h->opt_wide_stats ? stats : nullptr; cp.overflow_slots = overflow_slots;
+    hipLaunchKernelGGL(ifr::select_candidates_kernel, dim3((unsigned)n), dim3(ifr::BLOCK), 0, s, cp);
+    IFR_HIP(h, hipGetLastError());
+    // users whose buffer overflowed (scores rising with the item index: every item beats the bound of its time) are ranked
+    // from dense score rows instead; the one synchronisation of this entry point
+    unsigned long long back[3] = {0, 0, 0};            // overflow count (+ padding), candidates appended, candidates kept
+    IFR_HIP(h, hipMemcpyAsync(back, overflow_cnt, sizeof(back), hipMemcpyDeviceToHost, s));
+    IFR_HIP(h, hipStreamSynchronize(s));
+    const uint32_t n_over = (uint32_t)back[0];
+    h->wide_overflows += n_over;
+    if (h->opt_wide_stats) { h->wide_users += n; h->wide_cand += (double)back[1]; h->wide_kept += (double)back[2]; }
+    if (n_over == 0) return IFR_OK;
+    const int64_t ldr = ((int64_t)h->n_tiles * ifr::TILE_I + 3) / 4 * 4;
+    const int64_t rows = std::max<int64_t>(1, std::min<int64_t>(n_over, ((int64_t)1 << 28) / ldr));
+    const size_t fb_need = (size_t)rows * ldr * 4 + (size_t)rows * (4 + (size_t)K * 8) + 256;
+    rc = grow(h, &h->ws_sort, &h->ws_sort_bytes, fb_need);
+    if (rc) return rc;
+    float *rows_buf = (float *)h->ws_sort;
+    int32_t *fb_users = (int32_t *)((char *)h->ws_sort + (size_t)rows * ldr * 4);
+    int32_t *fb_ids = fb_users + rows;
+    float *fb_scores = (float *)(fb_ids + rows * K);
+    for (int64_t b = 0; b < n_over; b += rows) {
+        const int m = (int)std::min<int64_t>(rows, n_over - b);
+        hipLaunchKernelGGL(ifr::gather_ids_kernel, dim3((m + 255) / 256), dim3(256), 0, s, user_ids, overflow_slots + b, m, fb_users);
+        rc = ifr_score_dense(h, fb_users, m, rows_buf, ldr, s);
+        if (rc) return rc;
+        if (ifr::launch_select_topk(rows_buf, ldr, fb_users, m, (int)h->n_items, h->ex_ptr, h->ex_idx, h->ex_rows, K, fb_ids, fb_scores, s))
+            return fail(h, IFR_ERR_HIP, "ifr_rank_topk: fallback selection failed");
+        hipLaunchKernelGGL(ifr::scatter_rows_kernel, dim3((m * K + 255) / 256), dim3(256), 0, s, overflow_slots + b, m, K, fb_ids, fb_scores,
+                           out_ids, out_scores);
+        IFR_HIP(h, hipGetLastError());
+    }
+    return IFR_OK;
 }
 
 static int sum_columns(ifr_handle h, const double *per_user, const int32_t *evaluated, int64_t n, int ncol,
@@ -1140,6 +1257,31 @@ int ifr_debug_read_stamps(ifr_handle h, unsigned long long *out, int64_t cap, in
     IFR_HIP(h, hipDeviceSynchronize());
     *n = (int64_t)std::min<size_t>(h->dbg_stamp_count, (size_t)cap);
     if (*n > 0) IFR_HIP(h, hipMemcpy(out, h->ws_met, sizeof(unsigned long long) * (size_t)*n, hipMemcpyDeviceToHost));
+    return IFR_OK;
+}
+
+int ifr_wide_overflows(ifr_handle h, int64_t *count)
+{
+    if (!h || !count) return IFR_ERR_ARG;
+    *count = h->wide_overflows;
+    return IFR_OK;
+}
+
+int ifr_debug_wide_counts(ifr_handle h, uint32_t *out, int64_t cap, int64_t *n)
+{
+    if (!h || !out || !n) return IFR_ERR_ARG;
+    IFR_HIP(h, hipDeviceSynchronize());
+    *n = std::min<int64_t>(h->dbg_wide_n, cap);
+    if (*n > 0) IFR_HIP(h, hipMemcpy(out, h->dbg_wide_cnt, sizeof(uint32_t) * (size_t)*n, hipMemcpyDeviceToHost));
+    return IFR_OK;
+}
+
+int ifr_wide_stats(ifr_handle h, int64_t *users, double *candidates, double *kept)
+{
+    if (!h) return IFR_ERR_ARG;
+    if (users) *users = h->wide_users;
+    if (candidates) *candidates = h->wide_cand;
+    if (kept) *kept = h->wide_kept;
     return IFR_OK;
 }
 

@@ -29,6 +29,8 @@ constexpr int BLOCK = 256;
 constexpr int USERS_PER_BLOCK = 128;
 constexpr int PEND = 16;          // pending-candidate slots per lane (LDS)
 constexpr int NO_TILE = 0x7fffffff;
+constexpr int WIDE_AGE = 64;        // WIDE variant: tiles a pending entry may wait for its flush
+constexpr int WIDE_MAX_LISTS = 12;  // WIDE variant: lists per user (2 per item chunk)
 
 struct TopkParams {
     const float *U, *V, *ibase, *ubase;
@@ -56,6 +58,16 @@ struct TopkParams {
     float *part_scores;      // [n_slots][n_chunks*2][KL]
     int32_t *part_ids;
     uint32_t *lb;            // [n_slots padded to 128] per-user lower-bound keys, zeroed per call (may be null)
+    // WIDE variant (16 < K <= 128): the lane-private lists only yield bounds; every candidate that can still reach the
+    // user's top K is appended to the user's buffer in global memory and selected exactly afterwards
+    uint32_t *lbm;           // [n][wide_lists] per (user, list) word: key of the list's m_rank-th best score (0 = not that many yet)
+    int m_rank;              // ceil(K / wide_lists); 17 when the lists cannot hold K entries together (no bound from them)
+    uint32_t *started;       // [user tiles] workgroups of the user tile that have begun (zeroed per call)
+    uint32_t *bw;            // [n] per-user bound word: key of the best certified lower bound of the K-th best (0 = none)
+    int wide_lists;          // lists per user = 2 * n_chunks
+    uint2 *cand;             // [n][cand_cap] (score bits, item id), unordered
+    uint32_t *cand_cnt;      // [n] entries appended (may exceed cand_cap: overflow, the host falls back for that user)
+    int cand_cap;
     float *dense;            // STORE variant: also write every score, dense[slot][item] (may be null otherwise)
     int64_t dense_ld;        // floats per row, >= n_tiles * 32 and a multiple of 4
     unsigned long long *stamps;  // dev-only: [grid][4 waves][8] cycle sums per phase (debug bit 7), else null
@@ -124,7 +136,18 @@ __device__ __forceinline__ float list_tau(const float (&ls)[KL], int K)
 // STORE: the scores are also written out as dense rows (the same values ifr_score_dense computes), so that the
 // row-wise consumers (AUC, list metrics) cost one HBM pass instead of a second GEMM.  A user's 32 scores of a
 // tile are one 128-byte line, written as 8 x 16 bytes by the user's two half-lanes.
-template <int KD, int KL, bool HAS_BASE, bool STORE = false>
+// WIDE: cut-offs 16 < K <= 128.  A lane still keeps a sorted 16-list in registers, but only as a source of bounds: list
+// i of a user (one per half-lane and item chunk, L lists in all) publishes its m-th best score, m = ceil(K / L); the
+// L lists hold distinct items, so at least K items of the user score >= B = min_i (m-th best of list i), i.e. B is a
+// lower bound of the user's K-th best.  B goes to the user's bound word by atomicMax, and every lane re-reads that
+// word once per tile (the load has the whole tile to come back).  Every non-excluded score >= the bound is appended
+// to the user's candidate buffer in global memory (one returning atomic per lane and flush reserves the slots);
+// select_candidates_kernel then picks the exact top K.  Bounds only rise, a stale or missing word only costs
+// candidates, never a result.  Workgroups are numbered user-tile-major here so that the chunks of a user tile start
+// together and their words meet early; each takes every n_chunks-th tile, so that every list samples the whole
+// catalogue.  (Tried: the exact K-th best of the union of the lists from four published ranks per list -- 20 % fewer
+// candidates, but the 16-byte loads and 16 L compares per flush cost far more than they saved.)
+template <int KD, int KL, bool HAS_BASE, bool STORE = false, bool WIDE = false>
 __global__ __launch_bounds__(BLOCK, KD > 128 ? 1 : 2) void score_topk_kernel(TopkParams p)
 {
     constexpr int ROW = KD + 4;                 // padded LDS row (floats); +4 => conflict-free b128 reads
@@ -141,7 +164,14 @@ __global__ __launch_bounds__(BLOCK, KD > 128 ? 1 : 2) void score_topk_kernel(Top
     const int n_ut = (int)((p.n + USERS_PER_BLOCK - 1) / USERS_PER_BLOCK);
     int chunk, ut, chunk_tiles, lists;
     int64_t part_off = 0, slot0 = 0;
-    if ((int)blockIdx.x < p.gridA) {
+    if (WIDE) {
+        // user-tile-major: the chunks of a user tile are consecutive workgroups, dispatched together, so that the lists
+        // of a user fill side by side (speed only: any placement gives the same result)
+        ut = blockIdx.x / p.n_chunks;
+        chunk = blockIdx.x - ut * p.n_chunks;
+        chunk_tiles = p.chunk_tiles;
+        lists = 2 * p.n_chunks;
+    } else if ((int)blockIdx.x < p.gridA) {
         chunk = blockIdx.x / p.n_utA;
         ut = blockIdx.x - chunk * p.n_utA;
         chunk_tiles = p.chunk_tiles;
@@ -155,12 +185,34 @@ __global__ __launch_bounds__(BLOCK, KD > 128 ? 1 : 2) void score_topk_kernel(Top
         part_off = p.part_offB;
         slot0 = (int64_t)p.n_utA * USERS_PER_BLOCK;
     }
-    const int t0 = chunk * chunk_tiles;
-    const int t1 = min(t0 + chunk_tiles, p.n_tiles);
+    // Tiles of this workgroup: t0, t0 + ts, ... < t1.  Non-WIDE: a contiguous chunk (ts = 1).  WIDE: every n_chunks-th
+    // tile, so that each list sees a sample of the whole catalogue -- with contiguous chunks a catalogue sorted by
+    // score (popularity order) would leave the min-over-lists bound at the worst chunk's level.
+    const int ts = WIDE ? p.n_chunks : 1;
+    const int t0 = WIDE ? chunk : chunk * chunk_tiles;
+    const int t1 = WIDE ? t0 + ((p.n_tiles - chunk + ts - 1) / ts) * ts : min(t0 + chunk_tiles, p.n_tiles);
 
     const int64_t slot = (int64_t)ut * USERS_PER_BLOCK + wave * 32 + j;
     const bool live = slot < p.n;
     const int uid = (int)min((int64_t)max(p.user_ids[live ? slot : p.n - 1], 0), p.n_users - 1);
+
+    if (WIDE && p.n_chunks > 1) {
+        // Rendezvous of the user tile's workgroups.  Until every list of a user has published, the bound is -inf and a
+        // lane appends every score it sees; workgroups are dispatched in block order, but once the chip is full the
+        // next one only starts when a slot frees -- measured: siblings 30-60 tiles (and at a round boundary a whole
+        // workgroup's time) apart, 2-4 x the candidates.  So a workgroup waits for its siblings before its first
+        // tile.  They are the next blocks in dispatch order, so every other resident workgroup runs on and frees
+        // slots; the spin is bounded all the same (no ordering is promised): on a time-out the workgroup just
+        // proceeds with more candidates.
+        if (tid == 0) {
+            atomicAdd(&p.started[ut], 1u);
+            for (int spins = 0; spins < 200000; ++spins) {
+                if (__hip_atomic_load(&p.started[ut], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (uint32_t)p.n_chunks) break;
+                __builtin_amdgcn_s_sleep(64);
+            }
+        }
+        __syncthreads();
+    }
 
     // user factors: lane (j,h) keeps U[uid][8g + 4h + e], g < KD/8, e < 4
     f32x4 ureg[KD / 8];
@@ -201,8 +253,59 @@ __global__ __launch_bounds__(BLOCK, KD > 128 ? 1 : 2) void score_topk_kernel(Top
     // A lower bound L on the user's K-th best score (from the partner half-lane or from another
     // item chunk's workgroup, via p.lb) prunes with '>=': s > next_below(L).  The lane's own K-th
     // best prunes with '>' (its list only holds earlier, smaller item ids).
-    if (p.lb != nullptr) tau = next_below(key_to_float(p.lb[slot]));
-    auto flush = [&]() {
+    if (!WIDE && p.lb != nullptr) tau = next_below(key_to_float(p.lb[slot]));
+    if (WIDE && !live) tau = INFINITY;          // idle lanes of the last user tile must not append for user n - 1
+    uint32_t bw_seen = 0;
+    int age = 0;                                // WIDE: tiles since the last flush                       // WIDE: the user's bound word as loaded one tile ago
+    auto flush_wide = [&]() __attribute__((always_inline)) {
+        int maxc = cnt;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) maxc = max(maxc, __shfl_xor(maxc, off));
+        // every pending entry enters the lane's list; those that still reach the bound are the user's candidates
+        int keep = 0;
+        for (int q = 0; q < maxc; ++q) {
+            const uint2 e = pend[q][tid];
+            const float x = (q < cnt) ? __uint_as_float(e.x) : -INFINITY;     // -inf never inserts
+            list_insert<KL>(ls, li, x, (int)e.y);
+            keep += x > tau ? 1 : 0;
+        }
+        if (keep > 0) {
+            const uint32_t pos0 = atomicAdd(&p.cand_cnt[slot], (uint32_t)keep);
+            uint2 *dst = p.cand + slot * (int64_t)p.cand_cap;
+            uint32_t w = pos0;
+            for (int q = 0; q < cnt; ++q) {
+                const uint2 e = pend[q][tid];
+                if (__uint_as_float(e.x) > tau) { if (w < (uint32_t)p.cand_cap) dst[w] = e; ++w; }
+            }
+        }
+        cnt = 0;
+        age = 0;
+        if (live) {
+            uint32_t *words = p.lbm + slot * (int64_t)p.wide_lists;
+            // fewer than m entries yet (-inf), or lists too few to hold K entries together (m_rank > KL): "no bound", key 0
+            const float own = list_tau<KL>(ls, p.m_rank);
+            const uint32_t pub = (p.m_rank <= KL && own > -INFINITY) ? float_to_key(own) : 0u;
+            __hip_atomic_store(words + chunk * 2 + h, pub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            uint32_t mn = pub;
+            for (int i = 0; i < p.wide_lists; i += 4) {
+                const uint32_t a = __hip_atomic_load(words + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const uint32_t b = __hip_atomic_load(words + i + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const uint32_t c = i + 2 < p.wide_lists ? __hip_atomic_load(words + i + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ~0u;
+                const uint32_t d = i + 3 < p.wide_lists ? __hip_atomic_load(words + i + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ~0u;
+                mn = min(min(mn, a), min(b, min(c, d)));
+            }
+            float B = key_to_float(mn);
+            if (p.K <= 2 * KL) {
+                // K <= 32: the two half-lanes of the user hold K entries between them -- a bound that needs no other workgroup
+                const float half = list_tau<KL>(ls, (p.K + 1) >> 1);
+                B = fmaxf(B, fminf(half, __shfl_xor(half, 32)));
+            }
+            if (B > -INFINITY) atomicMax(&p.bw[slot], float_to_key(B));            // for the user's other lanes (per-tile refresh)
+            tau = fmaxf(tau, next_below(B));                                         // s > tau  <=>  s >= B
+        }
+    };
+    auto flush = [&]() __attribute__((always_inline)) {
+        if (WIDE) { flush_wide(); return; }
         int maxc = cnt;
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) maxc = max(maxc, __shfl_xor(maxc, off));
@@ -266,12 +369,18 @@ __global__ __launch_bounds__(BLOCK, KD > 128 ? 1 : 2) void score_topk_kernel(Top
     // the other), so no register hand-over sits between the last MFMA of a tile and the next tile.
     f32x16 accA = {0}, accB = {0};
     uint32_t mC = 0;
-    auto tile_step = [&](int t, const f32x16 &accC, f32x16 &accN) {
+    auto tile_step = [&](int t, const f32x16 &accC, f32x16 &accN, int parity) __attribute__((always_inline)) {
         unsigned long long T0 = 0, T1 = 0, T2 = 0;
         if (dbg_stamp) T0 = __builtin_amdgcn_s_memtime();
         const bool dbg_no_stage = (p.dbg & 7) >= 3;   // dev ablation: 3 = no staging, no barrier; 4 = no staging
-        const int buf = dbg_no_stage ? 0 : (t - t0) & 1;
-        if (t + 1 < t1 && !dbg_no_stage) stage_load(t + 1);
+        const int buf = dbg_no_stage ? 0 : parity;
+        if (WIDE && live) {
+            // the user's bound word, refreshed every tile: the value loaded during the last tile raises tau now, the
+            // next load is issued here and has a whole tile to come back (any workgroup of the user may have raised it)
+            tau = fmaxf(tau, next_below(key_to_float(bw_seen)));
+            bw_seen = __hip_atomic_load(p.bw + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (t + ts < t1 && !dbg_no_stage) stage_load(t + ts);
 
         // ---- zone A: 32 items x 32 users x KD on the matrix core (tile t), one k-group of four
         // MFMAs per step, each step followed by the branch-free part of the select for 128/KD score
@@ -283,7 +392,7 @@ __global__ __launch_bounds__(BLOCK, KD > 128 ? 1 : 2) void score_topk_kernel(Top
         accN = f32x16{0};
         const float *arow = &vt[buf][j][4 * h];
         const float seltau = (t > t0 && (p.dbg & 7) < 2) ? tau : INFINITY;
-        const int item0 = (t - 1) * TILE_I + 4 * h;
+        const int item0 = (t - ts) * TILE_I + 4 * h;          // the tile selected now: the previous one of this workgroup
         const uint32_t mm = mC >> (4 * h);
         float s[16], ibC[16];
         unsigned long long hb[16];              // per score register: ballot of the lanes whose score passes (SGPR pairs)
@@ -308,7 +417,7 @@ __global__ __launch_bounds__(BLOCK, KD > 128 ? 1 : 2) void score_topk_kernel(Top
                 s[r] = sc;
                 hb[r] = __ballot(sc > seltau);                                  // one v_cmp into an SGPR pair
                 if (STORE && (r & 3) == 3 && t > t0)                            // items item0 + 8q .. + 3 of tile t-1
-                    *reinterpret_cast<f32x4 *>(drow + (int64_t)(t - 1) * TILE_I + 2 * (r - 3)) =
+                    *reinterpret_cast<f32x4 *>(drow + (int64_t)(t - ts) * TILE_I + 2 * (r - 3)) =
                         f32x4{s[r - 3], s[r - 2], s[r - 1], sc};
             }
             a_cur = a_nxt;
@@ -353,6 +462,14 @@ __global__ __launch_bounds__(BLOCK, KD > 128 ? 1 : 2) void score_topk_kernel(Top
             }
             if (dbg_stamp) T2c = __builtin_amdgcn_s_memtime();
         }
+        // WIDE: the first tile's scores are all pending now; drain them at once, so that the list's bound word is
+        // published a tile earlier (until the user's words meet, every score is a candidate)
+        // ... and pending entries never wait longer than WIDE_AGE tiles: a lane's list -- hence the user's bound -- would
+        // otherwise lag by up to 16 entries per list, as much as K itself, once hits have become rare
+        if (WIDE) {
+            ++age;
+            if (t == t0 + ts || (age >= WIDE_AGE && __any(cnt > 0))) { flush(); age = 0; }
+        }
         // exclusion mask of tile t for the next iteration's select
         mC = 0;
         if (nt == t) {
@@ -361,11 +478,19 @@ __global__ __launch_bounds__(BLOCK, KD > 128 ? 1 : 2) void score_topk_kernel(Top
             ++ex_cur;
             if (ex_cur + 1 < ex_end) { const uint2 e = p.ex_pair[ex_cur + 1]; nt2 = (int)e.x; nm2 = e.y; } else nt2 = NO_TILE;
         }
+        if (WIDE) {
+            // entries of tiles that other workgroups (item chunks) of this user tile sweep
+            while (nt < t + ts) {
+                nt = nt2; nm = nm2;
+                ++ex_cur;
+                if (ex_cur + 1 < ex_end) { const uint2 e = p.ex_pair[ex_cur + 1]; nt2 = (int)e.x; nm2 = e.y; } else nt2 = NO_TILE;
+            }
+        }
         if (t == p.n_tiles - 1) {
             const int valid = p.n_items - t * TILE_I;       // 1..32
             if (valid < 32) mC |= ~0u << valid;
         }
-        if (t + 1 < t1 && !dbg_no_stage) stage_store(buf ^ 1);
+        if (t + ts < t1 && !dbg_no_stage) stage_store(buf ^ 1);
         if ((p.dbg & 7) != 3) __syncthreads();
         if (dbg_stamp) {
             const unsigned long long T3 = __builtin_amdgcn_s_memtime();
@@ -373,9 +498,9 @@ __global__ __launch_bounds__(BLOCK, KD > 128 ? 1 : 2) void score_topk_kernel(Top
             if (T2b) { ph4 += T2b - T2; ph5 += T2c - T2b; ph6 += 1; }
         }
     };
-    for (int t = t0; t <= t1; t += 2) {
-        tile_step(t, accA, accB);
-        if (t + 1 <= t1) tile_step(t + 1, accB, accA);
+    for (int t = t0; t <= t1; t += 2 * ts) {
+        tile_step(t, accA, accB, 0);
+        if (t + ts <= t1) tile_step(t + ts, accB, accA, 1);
     }
     if (dbg_stamp && lane == 0) {
         unsigned long long *o = p.stamps + ((int64_t)blockIdx.x * WAVES + wave) * 8;
@@ -384,7 +509,7 @@ __global__ __launch_bounds__(BLOCK, KD > 128 ? 1 : 2) void score_topk_kernel(Top
 
     // ---- final drain and write the lane's partial list
     flush();
-    if (live) {
+    if (live && !WIDE) {
         const int64_t base = part_off + ((slot - slot0) * lists + chunk * 2 + h) * KL;
 #pragma unroll
         for (int i = 0; i < KL; ++i) { p.part_scores[base + i] = ls[i]; p.part_ids[base + i] = li[i]; }
@@ -522,6 +647,85 @@ inline void launch_merge_topk(const float *part_scores, const int32_t *part_ids,
     else
         hipLaunchKernelGGL((merge_topk_kernel<KL>), dim3((unsigned)n), dim3(64), (size_t)n_lists * KL * 8, s, part_scores, part_ids, n,
                            n_lists, stride_lists, K, out_ids, out_scores);
+}
+
+// ------------------------------------------------------------------------------------
+// WIDE variant, second step: the exact top K of a user's candidate buffer (score desc, id asc).  One workgroup per
+// user.  The candidates are first cut with the final bound B (the user's bound word: at least K of them reach it), which leaves about 1.3 K of them; those are ranked by counting.  A buffer that overflowed is reported
+// in overflow_slots: the host ranks that user from a dense score row instead.
+// ------------------------------------------------------------------------------------
+constexpr int CAND_MAX = 16384;     // entries of a user's candidate buffer in global memory
+constexpr int CAND_KEEP = 2048;     // ... that may reach the final bound (LDS of the selection)
+
+struct CandParams {
+    const uint2 *cand;
+    const uint32_t *cand_cnt, *bw;
+    int cand_cap;
+    int64_t n;
+    int K;
+    int32_t *out_ids;
+    float *out_scores;
+    uint32_t *overflow_cnt;      // [1], zeroed per call
+    unsigned long long *stats;   // [2], zeroed per call: candidates appended, candidates that reach the final bound (null: not counted)
+    int32_t *overflow_slots;     // [n]
+};
+
+__global__ __launch_bounds__(BLOCK) void select_candidates_kernel(CandParams p)
+{
+    __shared__ unsigned long long keys[CAND_KEEP];
+    __shared__ uint32_t sbits[CAND_KEEP];
+    __shared__ int s_n;
+    const int tid = threadIdx.x;
+    const int64_t u = blockIdx.x;
+    const uint32_t total = p.cand_cnt[u];
+    const int K = p.K;
+    auto overflow = [&]() {
+        if (tid == 0) p.overflow_slots[atomicAdd(p.overflow_cnt, 1u)] = (int32_t)u;
+        for (int r = tid; r < K; r += BLOCK) { p.out_ids[u * K + r] = -1; p.out_scores[u * K + r] = -INFINITY; }
+    };
+    if (total > (uint32_t)p.cand_cap) { overflow(); return; }
+    const float thr = next_below(key_to_float(p.bw[u]));       // the final bound: at least K candidates reach it
+    if (tid == 0) s_n = 0;
+    __syncthreads();
+    const uint2 *src = p.cand + u * (int64_t)p.cand_cap;
+    for (uint32_t e = tid; e < total; e += BLOCK) {
+        const uint2 c = src[e];
+        const float x = __uint_as_float(c.x);
+        if (x > thr) {
+            const int pos = atomicAdd(&s_n, 1);
+            if (pos < CAND_KEEP) {
+                keys[pos] = ((unsigned long long)float_to_key(x + 0.0f) << 32) | (uint32_t)~c.y;     // + 0: -0 ties with +0
+                sbits[pos] = c.x;
+            }
+        }
+    }
+    __syncthreads();
+    const int nf = s_n;
+    if (nf > CAND_KEEP) { overflow(); return; }              // uniform: the bound stayed far below the K-th best
+    if (tid == 0 && p.stats != nullptr) { atomicAdd(&p.stats[0], (unsigned long long)total); atomicAdd(&p.stats[1], (unsigned long long)nf); }
+    for (int e = tid; e < nf; e += BLOCK) {
+        const unsigned long long k = keys[e];
+        int rank = 0;
+        for (int x = 0; x < nf; ++x) rank += keys[x] > k ? 1 : 0;
+        if (rank < K) { p.out_ids[u * K + rank] = (int32_t)~(uint32_t)k; p.out_scores[u * K + rank] = __uint_as_float(sbits[e]); }
+    }
+    for (int r = nf + tid; r < K; r += BLOCK) { p.out_ids[u * K + r] = -1; p.out_scores[u * K + r] = -INFINITY; }
+}
+
+// fallback plumbing for overflowed users: user ids of the flagged slots, and their rows back into place
+__global__ void gather_ids_kernel(const int32_t *user_ids, const int32_t *slots, int m, int32_t *out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < m) out[i] = user_ids[slots[i]];
+}
+__global__ void scatter_rows_kernel(const int32_t *slots, int m, int K, const int32_t *ids, const float *scores, int32_t *out_ids,
+                                    float *out_scores)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m * K) return;
+    const int r = i / K, c = i - r * K;
+    out_ids[(int64_t)slots[r] * K + c] = ids[i];
+    out_scores[(int64_t)slots[r] * K + c] = scores[i];
 }
 
 // ------------------------------------------------------------------------------------
@@ -710,7 +914,7 @@ __device__ __forceinline__ void store_at_k(double *out, double dcg, double idcg,
     out[5] = tp > 0 ? crr / icrr : 0.0;
 }
 
-// one thread per user; top-K lists of at most 32 entries (the fused kernel's output)
+// one thread per user; top-K lists of at most 128 entries (the fused kernel's output)
 __global__ __launch_bounds__(BLOCK) void metrics_topk_kernel(MetricParams p)
 {
     const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
@@ -726,12 +930,15 @@ __global__ __launch_bounds__(BLOCK) void metrics_topk_kernel(MetricParams p)
         return;
     }
     p.evaluated[i] = 1;
-    uint32_t hit = 0;
+    uint32_t hitw[4] = {0u, 0u, 0u, 0u};           // K <= 128 list positions
     int n_ranked = 0;
     for (int r = 0; r < p.K; ++r) {
-        const int id = p.topk[i * p.K + r];
+        const int id = p.topk[i * (int64_t)p.K + r];
         n_ranked += id >= 0 ? 1 : 0;
-        if (in_sorted_row(p.tr_idx, b, e, id)) hit |= 1u << r;
+        if (in_sorted_row(p.tr_idx, b, e, id)) {
+            const uint32_t bit = 1u << (r & 31);
+            if (r < 32) hitw[0] |= bit; else if (r < 64) hitw[1] |= bit; else if (r < 96) hitw[2] |= bit; else hitw[3] |= bit;
+        }
     }
     for (int q = 0; q < p.n_k; ++q) {
         const int k = p.ks[q];
@@ -739,7 +946,8 @@ __global__ __launch_bounds__(BLOCK) void metrics_topk_kernel(MetricParams p)
         int tp = 0;
         const int trunc = min(k, n_ranked);
         for (int r = 0; r < k; ++r) {
-            if (hit & (1u << r)) { dcg += p.discount[r]; crr += 1.0 / (double)(r + 1); ++tp; }
+            const uint32_t hw = r < 32 ? hitw[0] : r < 64 ? hitw[1] : r < 96 ? hitw[2] : hitw[3];
+            if (hw & (1u << (r & 31))) { dcg += p.discount[r]; crr += 1.0 / (double)(r + 1); ++tp; }
             if (r < n_pos) idcg += p.discount[r];
             if (r < n_pos && r < trunc) icrr += 1.0 / (double)(r + 1);
         }

@@ -12,7 +12,9 @@ from . import _lib
 
 METRICS_PER_K = 6      # ndcg, recall, precision, hit ratio, f1, ncrr (include/ifr.h IFR_METRICS_PER_K)
 METRIC_COLUMNS = ("ndcg", "recall", "precision", "hit", "f1", "ncrr")
-MAX_FUSED_TOPK = 32    # ifr_rank_topk (include/ifr.h IFR_MAX_TOPK)
+MAX_FUSED_TOPK = 128   # ifr_rank_topk, dot-product models (include/ifr.h IFR_MAX_TOPK)
+MAX_FUSED_TOPK_ITEM = 32   # ifr_rank_topk, item-item models (IFR_MAX_TOPK_ITEM)
+MAX_TOPK_METRICS = 128 # ifr_eval_topk_metrics
 MAX_SELECT_TOPK = 1024 # ifr_select_topk
 MAX_DENSE_METRIC_POS = 4096   # ifr_eval_dense_metrics: positives per row
 
@@ -249,8 +251,9 @@ class HipScorer:
 
     # ------------------------------------------------------------------ compute
     def rank_topk(self, user_ids, K, out_ids=None, out_scores=None, dense_batch_pairs=1 << 28):
-        """Top-K (ids int32 [n,K], scores fp32 [n,K]) for the listed users: the fused kernel up to K = 32, dense rows +
-        partial ranking up to K = 1024 (`dense_batch_pairs` bounds users x items of one dense batch)."""
+        """Top-K (ids int32 [n,K], scores fp32 [n,K]) for the listed users: the fused kernel up to K = 128 (item-item
+        models: 32), dense rows + partial ranking up to K = 1024 (`dense_batch_pairs` bounds users x items of one
+        dense batch)."""
         torch = _torch()
         u = self._dev_users(user_ids)
         n = u.numel()
@@ -258,7 +261,7 @@ class HipScorer:
             out_ids = torch.empty((n, K), dtype=torch.int32, device=self.device)
         if out_scores is None:
             out_scores = torch.empty((n, K), dtype=torch.float32, device=self.device)
-        if K <= MAX_FUSED_TOPK:
+        if K <= self.max_fused_topk():
             self._check(self._lib.ifr_rank_topk(self._h, u.data_ptr(), n, int(K), out_ids.data_ptr(),
                                                 out_scores.data_ptr(), self._stream()))
             return out_ids, out_scores
@@ -272,12 +275,29 @@ class HipScorer:
             self.select_topk(ub, dense, K, out_ids[b:b + step], out_scores[b:b + step])
         return out_ids, out_scores
 
+    def max_fused_topk(self):
+        """Largest K ifr_rank_topk serves for the model that is set."""
+        return MAX_FUSED_TOPK if self.item_model is None else MAX_FUSED_TOPK_ITEM
+
+    def wide_overflows(self):
+        """Users the 16 < K <= 128 path ranked from dense rows so far because their candidate buffer overflowed."""
+        c = ctypes.c_int64(0)
+        self._check(self._lib.ifr_wide_overflows(self._h, ctypes.byref(c)))
+        return c.value
+
+    def wide_stats(self):
+        """(users ranked by the 16 < K <= 128 path, candidates appended, candidates kept after the final bound)."""
+        u, c, k = ctypes.c_int64(0), ctypes.c_double(0), ctypes.c_double(0)
+        self._check(self._lib.ifr_wide_stats(self._h, ctypes.byref(u), ctypes.byref(c), ctypes.byref(k)))
+        return u.value, c.value, k.value
+
     NOALLOC_MAX_USERS = 65536     # ifr_rank_topk_noalloc (IFR_NOALLOC_MAX_USERS)
+    NOALLOC_MAX_TOPK = 16         # IFR_NOALLOC_MAX_TOPK
 
     def rank_topk_noalloc(self, user_ids, K, out_ids, out_scores):
         """ifr_rank_topk_noalloc: rank_topk for callers that cannot allocate (HIP graph capture, serving loops).  The
         library call allocates nothing -- its workspace is a static device array -- so `user_ids` (int32 device tensor)
-        and both outputs must be the caller's own preallocated device tensors.  Dot-product models, K <= 32,
+        and both outputs must be the caller's own preallocated device tensors.  Dot-product models, K <= 16,
         at most NOALLOC_MAX_USERS users per call; calls that overlap on one GPU race (include/ifr.h).  User rows
         are not range-checked here (the check would allocate); the kernel clamps them into [0, n_users)."""
         torch = _torch()
@@ -291,10 +311,10 @@ class HipScorer:
                                                     out_scores.data_ptr(), self._stream()))
         return out_ids, out_scores
 
-    MAX_TOPK_WITH_DENSE = 32      # ifr_rank_topk_dense (= IFR_MAX_TOPK)
+    MAX_TOPK_WITH_DENSE = 128     # ifr_rank_topk_dense (= IFR_MAX_TOPK)
 
     def can_rank_topk_dense(self, K):
-        """True when rank_topk_dense serves this model and cut-off in one kernel (dot-product model, K <= 32, no
+        """True when rank_topk_dense serves this model and cut-off in one kernel (dot-product model, K <= 128, no
         unknown catalogue items to pad)."""
         return self.item_model is None and 1 <= int(K) <= self.MAX_TOPK_WITH_DENSE and \
             max(getattr(self, "catalogue_items", 0), self.n_items) == self.n_items

@@ -16,8 +16,8 @@ from . import dist as ifr_dist
 from .engine import MAX_DENSE_METRIC_POS, METRIC_COLUMNS, METRICS_PER_K
 from .metrics import metric_kind
 
-MAX_FUSED_K = 32          # fused score + top-K kernel; larger cut-offs, k = -1, MRR and MAP take dense rows +
-                          # ifr_eval_dense_metrics (positions of the positives by counting)
+MAX_FUSED_K = 128         # fused score + top-K kernel of dot-product models (item-item models: 32); larger cut-offs,
+MAX_FUSED_K_ITEM = 32     # k = -1, MRR and MAP take dense rows + ifr_eval_dense_metrics (positions of the positives by counting)
 
 
 # --------------------------------------------------------------------------- CSR preparation
@@ -238,8 +238,9 @@ def export_candidate_pools(model, pool_size, batch_users=1 << 16, _engine=None):
 
 
 # --------------------------------------------------------------------------- metric plan
-def plan_metrics(metrics):
-    """-> (specs, fused_ks, list_ks, need_auc, need_list).  specs[i] = (kind, k) of metrics[i]."""
+def plan_metrics(metrics, max_fused_k=MAX_FUSED_K):
+    """-> (specs, ks, need_auc, need_list).  specs[i] = (kind, k) of metrics[i]; need_list: some metric needs the dense
+    rows (a cut-off beyond the fused kernel's `max_fused_k`, k = -1, MRR, MAP)."""
     specs = []
     for mt in metrics:
         kind = metric_kind(mt)
@@ -248,7 +249,7 @@ def plan_metrics(metrics):
             raise ValueError("list-valued k must be expanded by the caller (BaseMethod.organize_metrics does)")
         specs.append((kind, int(k)))
     per_k = [(kind, k) for kind, k in specs if kind in METRIC_COLUMNS]
-    need_list = any(kind in ("mrr", "map") for kind, _ in specs) or any(k <= 0 or k > MAX_FUSED_K for _, k in per_k)
+    need_list = any(kind in ("mrr", "map") for kind, _ in specs) or any(k <= 0 or k > max_fused_k for _, k in per_k)
     need_auc = any(kind == "auc" for kind, _ in specs)
     ks = sorted({k for _, k in per_k}, key=lambda v: (v <= 0, v))
     return specs, ks, need_auc, need_list
@@ -286,13 +287,15 @@ def ranking_eval(model, metrics, train_set, test_set, val_set=None, rating_thres
     if len(metrics) == 0:
         return [], []
     import torch
-    specs, ks, need_auc, need_list = plan_metrics(metrics)
+    plan_metrics(metrics)                          # validates the metric list before anything else
     if not getattr(model, "is_fitted", False):
         raise RuntimeError("Model is not fitted. Please call `model.fit()` before ranking.")
     if _engine is None and not hasattr(model, "_hip_engine"):
         raise TypeError("ranking_eval needs a model with the HIP scoring path (recommenders_amd.models.HipScoringMixin); "
                         "there is no CPU fallback")
     eng = model._hip_engine() if _engine is None else _engine
+    specs, ks, need_auc, need_list = plan_metrics(
+        metrics, eng.max_fused_topk() if hasattr(eng, "max_fused_topk") else MAX_FUSED_K_ITEM)
 
     n_items = train_set.num_items if exclude_unknowns else test_set.num_items
     if n_items < eng.n_items:

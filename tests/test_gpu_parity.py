@@ -392,9 +392,9 @@ def test_topk_with_dense_rows_in_one_launch(torch, k, bias, K, chunks):
     assert torch.isnan(buf[users.numel():]).all() and torch.isnan(buf[:, 3008:]).all()      # nothing written beside the rows
     ids2, sc2, rows2 = sc.rank_topk_dense(users[:5], K)                                       # allocates its own rows
     assert torch.equal(ids2, ids0[:5]) and torch.equal(rows2, rows0[:5])
-    assert not sc.can_rank_topk_dense(33)
+    assert sc.can_rank_topk_dense(128) and not sc.can_rank_topk_dense(129)
     with pytest.raises(IfrError):
-        sc.rank_topk_dense(users, 33)
+        sc.rank_topk_dense(users, 129)
     with pytest.raises(ValueError):
         sc.rank_topk_dense(users, K, torch.empty((users.numel(), 2999), dtype=torch.float32, device="cuda"))
 
@@ -490,3 +490,83 @@ def test_target_shape_one_million_items_bit_exact(torch):
     np.testing.assert_array_equal(dense.cpu().numpy(), sc.score_dense(few).cpu().numpy())
     o_dense = orc.c_score_factor(U[few[0]], V, ib, float(ub[few[0]]), sc.chain_order()[sc.chain_order() < k])
     np.testing.assert_array_equal(dense[0].cpu().numpy(), o_dense)
+
+
+# ------------------------------------------------------------------ 16 < K <= 128: candidate buffers + exact selection
+@pytest.mark.parametrize("k,bias,K,n_items", [(128, False, 17, 3001), (50, True, 20, 3001), (128, True, 33, 20000),
+                                              (64, False, 64, 20000), (128, False, 100, 26744), (200, True, 128, 9000),
+                                              (32, True, 100, 1500)])           # 1500 items: the lists cannot bound K = 100
+def test_wide_topk_bit_exact_vs_oracle(torch, k, bias, K, n_items):
+    w = _workload(3000 + k + K, 333, n_items, k, bias)
+    sc = _scorer(w)
+    users = np.arange(w["n_users"], dtype=np.int32)
+    ids, scores = sc.rank_topk(users, K)
+    o_ids, o_sc, _, _ = _oracle(w, users, [K], K, sc.chain_order())
+    np.testing.assert_array_equal(ids.cpu().numpy(), o_ids)
+    np.testing.assert_array_equal(scores.cpu().numpy(), o_sc)
+    assert sc.wide_overflows() == 0
+    # placement independent: any chunk count gives the same lists
+    for chunks in (1, 5):
+        sc.set_option("chunks", chunks)
+        ids2, scores2 = sc.rank_topk(users[:140], K)
+        np.testing.assert_array_equal(ids2.cpu().numpy(), o_ids[:140])
+        np.testing.assert_array_equal(scores2.cpu().numpy(), o_sc[:140])
+
+
+def test_wide_topk_metrics_and_dense_rows(torch):
+    w = _workload(41, 500, 8000, 128, True)
+    sc = _scorer(w)
+    users = np.arange(w["n_users"], dtype=np.int32)
+    ks = [100, 50, 10]
+    ids, scores, dense = sc.rank_topk_dense(users, 100)
+    o_ids, o_sc, o_met, o_ev = _oracle(w, users, ks, 100, sc.chain_order())
+    np.testing.assert_array_equal(ids.cpu().numpy(), o_ids)
+    np.testing.assert_array_equal(scores.cpu().numpy(), o_sc)
+    np.testing.assert_array_equal(dense.cpu().numpy(), sc.score_dense(users).cpu().numpy())
+    per_user, evaluated, sums = sc.eval_topk_metrics(users, ids, ks)
+    ev = o_ev.astype(bool)
+    np.testing.assert_array_equal(evaluated.cpu().numpy(), o_ev)
+    cols = [6 * q + c for q in range(len(ks)) for c in range(3)]        # ndcg, recall, precision of each cut-off
+    np.testing.assert_allclose(per_user.cpu().numpy()[ev][:, cols], o_met[ev][:, : 3 * len(ks)], rtol=0, atol=1e-12)
+
+
+def test_wide_topk_ties_short_lists_and_overflow_fallback(torch):
+    from recommenders_amd import HipScorer
+    # constant scores: canonical order = ascending item index; exclusions drop items 0 and 3
+    n_users, n_items, k = 130, 5000, 32
+    w = dict(U=np.ones((n_users, k), np.float32), V=np.ones((n_items, k), np.float32), ubase=None, ibase=None,
+             excl_ptr=np.arange(n_users + 1, dtype=np.int64) * 2, excl_idx=np.tile(np.array([0, 3], np.int32), n_users),
+             truth_ptr=np.zeros(n_users + 1, np.int64), truth_idx=np.zeros(0, np.int32), n_users=n_users, n_items=n_items, k=k)
+    sc = _scorer(w, truth=False)
+    ids, scores = sc.rank_topk(np.arange(n_users, dtype=np.int32), 40)
+    expect = np.setdiff1d(np.arange(42), [0, 3]).astype(np.int32)
+    np.testing.assert_array_equal(ids.cpu().numpy(), np.tile(expect, (n_users, 1)))
+    # fewer candidates than K
+    rng = np.random.default_rng(3)
+    excl = [np.arange(90), np.arange(60), np.zeros(0, int), np.arange(5, 90), np.arange(1, 90)]
+    w2 = dict(U=rng.normal(size=(5, 16)).astype(np.float32), V=rng.normal(size=(90, 16)).astype(np.float32), ubase=None, ibase=None,
+              excl_ptr=np.cumsum([0] + [len(e) for e in excl]).astype(np.int64), excl_idx=np.concatenate(excl).astype(np.int32),
+              truth_ptr=np.zeros(6, np.int64), truth_idx=np.zeros(0, np.int32), n_users=5, n_items=90, k=16)
+    sc2 = _scorer(w2, truth=False)
+    u5 = np.arange(5, dtype=np.int32)
+    ids, scores = sc2.rank_topk(u5, 50)
+    o_ids, o_sc, _, _ = _oracle(w2, u5, [50], 50, sc2.chain_order())
+    np.testing.assert_array_equal(ids.cpu().numpy(), o_ids)
+    np.testing.assert_array_equal(scores.cpu().numpy(), o_sc)
+    # scores that rise with the item index: every item beats the bound of its time, the candidate buffers overflow and
+    # those users are ranked from dense rows -- same lists, and the health counter says so
+    n_items = 40000
+    V = np.zeros((n_items, 32), np.float32)
+    V[:, 0] = np.arange(n_items, dtype=np.float32) * 1e-3
+    U = np.zeros((200, 32), np.float32)
+    U[:, 0] = 1.0
+    U[150:, 0] = -1.0                       # these users see falling scores: no overflow
+    w3 = dict(U=U, V=V, ubase=None, ibase=None, excl_ptr=np.arange(201, dtype=np.int64), excl_idx=np.full(200, n_items - 1, np.int32),
+              truth_ptr=np.zeros(201, np.int64), truth_idx=np.zeros(0, np.int32), n_users=200, n_items=n_items, k=32)
+    sc3 = _scorer(w3, truth=False)
+    u3 = np.arange(200, dtype=np.int32)
+    ids, scores = sc3.rank_topk(u3, 64)
+    o_ids, o_sc, _, _ = _oracle(w3, u3, [64], 64, sc3.chain_order())
+    np.testing.assert_array_equal(ids.cpu().numpy(), o_ids)
+    np.testing.assert_array_equal(scores.cpu().numpy(), o_sc)
+    assert 0 < sc3.wide_overflows() <= 150

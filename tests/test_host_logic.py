@@ -222,7 +222,8 @@ def test_plan_metrics_and_names():
     specs, ks, need_auc, need_list = ifr_eval.plan_metrics([M.NDCG(k=10), M.Recall(k=10), M.Precision(k=5)])
     assert specs == [("ndcg", 10), ("recall", 10), ("precision", 5)] and ks == [5, 10] and not need_auc and not need_list
     assert ifr_eval.plan_metrics([M.AUC()])[2] is True
-    assert ifr_eval.plan_metrics([M.NDCG()])[3] is True and ifr_eval.plan_metrics([M.Recall(k=100)])[3] is True
+    assert ifr_eval.plan_metrics([M.NDCG()])[3] is True and ifr_eval.plan_metrics([M.Recall(k=200)])[3] is True
+    assert ifr_eval.plan_metrics([M.Recall(k=100)])[3] is False and ifr_eval.plan_metrics([M.Recall(k=100)], 32)[3] is True
     assert M.NDCG(k=10).name == "NDCG@10" and M.NDCG().name == "NDCG@-1" and M.FMeasure(k=2).name == "F1@2"
     assert M.AUC().name == "AUC" and M.MRR().name == "MRR" and M.MAP().name == "MAP" and M.NDCG().type == "ranking"
     with pytest.raises(TypeError):

@@ -29,7 +29,7 @@ def _scorer(seed, n_users, n_items, k, bias):
     return sc
 
 
-@pytest.mark.parametrize("k,bias,K", [(128, False, 10), (50, True, 20)])
+@pytest.mark.parametrize("k,bias,K", [(128, False, 10), (50, True, 16)])
 def test_noalloc_matches_rank_topk_on_two_calls_in_a_row(torch, k, bias, K):
     sc = _scorer(77 + K, 5000, 6007, k, bias)
     dev = sc.device
@@ -61,13 +61,16 @@ def test_noalloc_rejects_what_does_not_fit(torch):
     scores = torch.empty((n, 10), dtype=torch.float32, device=dev)
     with pytest.raises(IfrError, match="IFR_NOALLOC_MAX_USERS"):
         sc.rank_topk_noalloc(users, 10, ids, scores)
-    # the largest batch that is accepted still runs, with the widest lists (K > 16)
+    with pytest.raises(IfrError, match=r"K must be in \[1, 16\]"):
+        sc.rank_topk_noalloc(users[:10].contiguous(), 20, torch.empty((10, 20), dtype=torch.int32, device=dev),
+                             torch.empty((10, 20), dtype=torch.float32, device=dev))
+    # the largest batch that is accepted still runs, with the longest lists
     n = sc.NOALLOC_MAX_USERS
     users = torch.arange(n, dtype=torch.int32, device=dev) % 300
-    ids = torch.empty((n, 20), dtype=torch.int32, device=dev)
-    scores = torch.empty((n, 20), dtype=torch.float32, device=dev)
-    sc.rank_topk_noalloc(users, 20, ids, scores)
-    e_ids, e_scores = sc.rank_topk(users[:300], 20)
+    ids = torch.empty((n, 16), dtype=torch.int32, device=dev)
+    scores = torch.empty((n, 16), dtype=torch.float32, device=dev)
+    sc.rank_topk_noalloc(users, 16, ids, scores)
+    e_ids, e_scores = sc.rank_topk(users[:300], 16)
     np.testing.assert_array_equal(ids[:300].cpu().numpy(), e_ids.cpu().numpy())
     np.testing.assert_array_equal(ids[300:600].cpu().numpy(), e_ids.cpu().numpy())
     np.testing.assert_array_equal(scores[:300].cpu().numpy(), e_scores.cpu().numpy())
