@@ -21,10 +21,12 @@ MAX_FUSED_K_ITEM = 32     # k = -1, MRR and MAP take dense rows + ifr_eval_dense
 
 
 # --------------------------------------------------------------------------- CSR preparation
-def _positive_csr(mat, thr, n_rows, n_cols):
-    """Rows of `mat` restricted to rating >= thr and item < n_cols, as a boolean CSR with
+def _positive_csr(mat, thr, n_rows, n_cols, row0=0):
+    """Rows [row0, row0 + n_rows) of `mat` restricted to rating >= thr and item < n_cols, as a boolean CSR with
     n_rows rows (rows beyond mat.shape[0] are empty: base_method.py:266-270)."""
     mat = sp.csr_matrix(mat)
+    if row0 or n_rows < mat.shape[0]:
+        mat = mat[row0:min(row0 + n_rows, mat.shape[0])]
     keep = mat.data >= thr
     coo_rows = np.repeat(np.arange(mat.shape[0]), np.diff(mat.indptr))[keep]
     cols = mat.indices[keep]
@@ -35,21 +37,28 @@ def _positive_csr(mat, thr, n_rows, n_cols):
     return out
 
 
-def build_eval_csrs(train_mat, test_mat, val_mat, rating_threshold, n_items, n_rows):
-    """-> (truth CSR, exclusion CSR, evaluated-candidate users) per base_method.py:246-283.
-
-    truth[u]     = test items rated >= threshold, clipped to [0, n_items)            (gt_pos)
-    exclusion[u] = (train U validation items rated >= threshold) minus truth[u]     (not ranked)
-    has_pos[u]   = user has a test item rated >= threshold *before* clipping (:257-259)."""
+def users_with_positives(test_mat, rating_threshold, n_rows):
+    """has_pos[u]: user u has a test item rated >= threshold *before* clipping to the catalogue (base_method.py:257-259)."""
     test_mat = sp.csr_matrix(test_mat)
     keep = test_mat.data >= rating_threshold
     rows = np.repeat(np.arange(test_mat.shape[0]), np.diff(test_mat.indptr))[keep]
     has_pos = np.zeros(n_rows, bool)
     has_pos[rows[rows < n_rows]] = True
-    truth = _positive_csr(test_mat, rating_threshold, n_rows, n_items)
-    excl = _positive_csr(train_mat, rating_threshold, n_rows, n_items)
+    return has_pos
+
+
+def build_eval_csrs(train_mat, test_mat, val_mat, rating_threshold, n_items, n_rows, row0=0):
+    """-> (truth CSR, exclusion CSR, has_pos) for the users [row0, row0 + n_rows) per base_method.py:246-283 (row i of
+    the results is user row0 + i: a rank of a sharded evaluation only builds its own users' rows).
+
+    truth[u]     = test items rated >= threshold, clipped to [0, n_items)            (gt_pos)
+    exclusion[u] = (train U validation items rated >= threshold) minus truth[u]     (not ranked)
+    has_pos[u]   = user has a test item rated >= threshold *before* clipping (:257-259)."""
+    has_pos = users_with_positives(test_mat, rating_threshold, row0 + n_rows)[row0:]
+    truth = _positive_csr(test_mat, rating_threshold, n_rows, n_items, row0)
+    excl = _positive_csr(train_mat, rating_threshold, n_rows, n_items, row0)
     if val_mat is not None:
-        excl = excl + _positive_csr(val_mat, rating_threshold, n_rows, n_items)
+        excl = excl + _positive_csr(val_mat, rating_threshold, n_rows, n_items, row0)
     excl = excl - excl.multiply(truth)              # test positives stay candidates (mask sum = 1)
     excl.eliminate_zeros()
     excl.sort_indices()
@@ -59,27 +68,112 @@ def build_eval_csrs(train_mat, test_mat, val_mat, rating_threshold, n_items, n_r
 # Experiment / hyper-parameter search evaluate many models on the same splits (base_method.py:1106-1116,
 # hyperopt.py:151-159): the CSRs above depend only on the splits, so the last few are kept.
 _EVAL_CSR_CACHE = []
-_EVAL_CSR_CACHE_SIZE = 4
+_EVAL_CSR_CACHE_SIZE = 8
+_FINGERPRINT_FULL_NNZ = 1 << 20
 
 
 def _fingerprint(mat):
+    """Cheap content fingerprint of a CSR matrix: shape, nnz and checksums of its three arrays -- over every entry up
+    to 2^20 stored ratings, over about 2^16 evenly strided samples beyond (a repeated evaluation at 20 M ratings
+    would otherwise spend more time summing ratings than ranking).  An in-place edit of a large matrix that misses
+    every sample goes unnoticed: call `clear_eval_cache()` after editing a split in place."""
     if mat is None:
         return None
     m = sp.csr_matrix(mat)
-    return (m.shape, m.nnz, float(m.data.sum()), int(m.indices[::97].sum()), int(m.indptr[::97].sum()))
+    step = 1 if m.nnz <= _FINGERPRINT_FULL_NNZ else max(1, m.nnz >> 16)
+    return (m.shape, m.nnz, float(m.data[::step].sum(dtype=np.float64)), int(m.indices[::max(97, step)].sum(dtype=np.int64)),
+            int(m.indptr[::97].sum(dtype=np.int64)))
 
 
-def cached_eval_csrs(train_mat, test_mat, val_mat, rating_threshold, n_items, n_rows):
-    """build_eval_csrs, memoised on the identity of the three matrices plus a cheap content fingerprint
-    (shape, nnz, sum of ratings, strided index checksums), so that in-place edits are noticed."""
-    key = (float(rating_threshold), int(n_items), int(n_rows), _fingerprint(train_mat), _fingerprint(test_mat), _fingerprint(val_mat))
+def clear_eval_cache():
+    """Forget the memoised evaluation CSRs (after editing a split in place)."""
+    del _EVAL_CSR_CACHE[:]
+
+
+def _cached(kind, mats, key, build):
     for ent in _EVAL_CSR_CACHE:
-        if ent[0] is train_mat and ent[1] is test_mat and ent[2] is val_mat and ent[3] == key:
-            return ent[4]
-    out = build_eval_csrs(train_mat, test_mat, val_mat, rating_threshold, n_items, n_rows)
-    _EVAL_CSR_CACHE.insert(0, (train_mat, test_mat, val_mat, key, out))
+        if ent[0] == kind and len(ent[1]) == len(mats) and all(a is b for a, b in zip(ent[1], mats)) and ent[2] == key:
+            return ent[3]
+    out = build()
+    _EVAL_CSR_CACHE.insert(0, (kind, mats, key, out))
     del _EVAL_CSR_CACHE[_EVAL_CSR_CACHE_SIZE:]
     return out
+
+
+def cached_eval_csrs(train_mat, test_mat, val_mat, rating_threshold, n_items, n_rows, row0=0):
+    """build_eval_csrs, memoised on the identity of the three matrices plus a cheap content fingerprint
+    (shape, nnz, checksums), so that in-place edits are noticed."""
+    key = (float(rating_threshold), int(n_items), int(n_rows), int(row0), _fingerprint(train_mat), _fingerprint(test_mat),
+           _fingerprint(val_mat))
+    return _cached("csrs", (train_mat, test_mat, val_mat), key,
+                   lambda: build_eval_csrs(train_mat, test_mat, val_mat, rating_threshold, n_items, n_rows, row0))
+
+
+def cached_users_with_positives(test_mat, rating_threshold, n_rows):
+    key = (float(rating_threshold), int(n_rows), _fingerprint(test_mat))
+    return _cached("has_pos", (test_mat,), key, lambda: users_with_positives(test_mat, rating_threshold, n_rows))
+
+
+class UserResults(Mapping):
+    """`user_results[i]` of ranking_eval: user index -> metric value, like the reference's dict
+    (base_method.py:236-239, 299), but backed by two arrays: building 138 K-entry dicts per metric cost more than the
+    ranking itself.  Reads like a dict (`[]`, `in`, `len`, iteration, `.items()`, `.values()`, `==` with a dict) and
+    pickles as a plain dict."""
+
+    __slots__ = ("_users", "_values")
+
+    def __init__(self, users, values):
+        users = np.asarray(users, np.int64)
+        values = np.asarray(values, np.float64)
+        if len(users) > 1 and not (users[1:] > users[:-1]).all():
+            order = np.argsort(users, kind="stable")
+            users, values = users[order], values[order]
+        self._users, self._values = users, values
+
+    def __getitem__(self, u):
+        i = int(np.searchsorted(self._users, u))
+        if i >= len(self._users) or self._users[i] != u:
+            raise KeyError(u)
+        return float(self._values[i])
+
+    def __contains__(self, u):
+        i = int(np.searchsorted(self._users, u))
+        return i < len(self._users) and self._users[i] == u
+
+    def __iter__(self):
+        return iter(self._users.tolist())
+
+    def __len__(self):
+        return len(self._users)
+
+    def keys(self):
+        return self._users.tolist()
+
+    def values(self):
+        return self._values.tolist()
+
+    def items(self):
+        return zip(self._users.tolist(), self._values.tolist())
+
+    def arrays(self):
+        """(users int64 ascending, values float64): the backing arrays, for vectorised consumers."""
+        return self._users, self._values
+
+    def to_dict(self):
+        return dict(self.items())
+
+    def __eq__(self, other):
+        if isinstance(other, UserResults):
+            return np.array_equal(self._users, other._users) and np.array_equal(self._values, other._values, equal_nan=True)
+        if isinstance(other, Mapping):
+            return self.to_dict() == dict(other)
+        return NotImplemented
+
+    def __repr__(self):
+        return f"UserResults({len(self)} users)"
+
+    def __reduce__(self):
+        return (dict, (self.to_dict(),))
 
 
 # --------------------------------------------------------------------------- lazy result caches
@@ -126,22 +220,91 @@ class LazyRankCache(Mapping):
 
 
 class _CacheOwner:
-    """Holds what is needed to rebuild one user's full ranking exactly as the batched
-    evaluation saw it (same candidate set)."""
+    """Holds what is needed to rebuild a user's full ranking exactly as the batched evaluation saw it (same candidate
+    set).  `excl` holds the exclusion rows of users [row0, row0 + excl.shape[0]).
 
-    def __init__(self, model, excl, n_items, users):
-        self.model, self.excl, self.n_items, self.users = model, excl, n_items, users
+    A first access to a lazy user materialises a whole BLOCK of lazy users in one pass -- dense score rows, one
+    segmented sort, candidate lists and aligned scores by device-side compaction, three device-to-host copies --
+    because callers that read the caches walk over many users (re-rankers, save_recommendations,
+    static_rerank_evaluator.py:262-296); one launch + copy per user costs 250 us, the block path a few tens."""
+
+    block_pairs = 1 << 27          # users x items of one materialisation block (at most `block_users` users)
+    block_users = 2048
+
+    def __init__(self, model, excl, n_items, users, row0=0):
+        self.model, self.excl, self.n_items, self.users, self.row0 = model, excl, n_items, users, int(row0)
+
+    def excl_row(self, u):
+        r = int(u) - self.row0
+        return self.excl[r].indices if 0 <= r < self.excl.shape[0] else np.zeros(0, np.int32)
+
+    def excl_global(self):
+        """The exclusion CSR with one row per user index from 0 (what an engine holding all users indexes)."""
+        if self.row0 == 0:
+            return self.excl
+        g = getattr(self, "_excl_global", None)
+        if g is None:
+            g = sp.vstack([sp.csr_matrix((self.row0, self.excl.shape[1]), dtype=self.excl.dtype), self.excl]).tocsr()
+            self._excl_global = g
+        return g
+
+    def _materialise_one(self, u):
+        mask = np.ones(self.n_items, bool)
+        mask[self.excl_row(u)] = False
+        cand = np.nonzero(mask)[0]
+        # model.rank refills the three caches itself (recommender.py:655-659)
+        return self.model.rank(user_idx=u, item_indices=cand, k=-1)
 
     def _materialise_cached_user(self, u):
         m = self.model
-        row = self.excl[u] if u < self.excl.shape[0] else None
-        mask = np.ones(self.n_items, bool)
-        if row is not None:
-            mask[row.indices] = False
-        cand = np.nonzero(mask)[0]
-        # model.rank refills the three caches itself (recommender.py:655-659)
-        ranked_items, item_scores = m.rank(user_idx=u, item_indices=cand, k=-1)
-        return ranked_items, item_scores
+        eng = m._hip_engine() if hasattr(m, "_hip_engine") else None
+        caches = (getattr(m, "ranked_items", None), getattr(m, "item_scores", None), getattr(m, "item_scores_mapped_indices", None))
+        if eng is None or not all(isinstance(c, LazyRankCache) for c in caches) or not hasattr(eng, "rank_full") \
+                or getattr(getattr(eng, "device", None), "type", "cpu") != "cuda" or self.n_items != eng.n_items:
+            return self._materialise_one(u)
+        import torch
+        done = caches[0]._explicit
+        pos = int(np.searchsorted(self.users, u))
+        b_max = max(1, min(self.block_users, self.block_pairs // max(1, self.n_items)))
+        block = [int(v) for v in self.users[pos:pos + 4 * b_max] if int(v) not in done and 0 <= int(v) < eng.n_users
+                 and m._hip_user_row(int(v)) == int(v)][:b_max]
+        if u not in block:                                 # a user the engine has no row of its own for
+            return self._materialise_one(u)
+        excl = self.excl_global()
+        if getattr(eng, "exclusion_source", None) is not excl:
+            eng.set_exclusion_csr(excl.indptr.astype(np.int64), excl.indices.astype(np.int32))
+            eng.exclusion_source = excl
+        eng.set_catalogue_items(self.n_items)
+        rows = torch.as_tensor(np.asarray(block, np.int32), device=eng.device)
+        dense = eng.score_dense(rows)                                        # [b, n_items]
+        ranked, n_cand = eng.rank_full(rows, dense)
+        # candidates in ascending item index and the scores aligned with them (recommender.py:643): compaction of
+        # the not-excluded columns, row by row
+        keep = torch.ones(dense.shape, dtype=torch.bool, device=eng.device)
+        lens = np.asarray([len(self.excl_row(v)) for v in block])
+        if lens.sum():
+            r_idx = torch.as_tensor(np.repeat(np.arange(len(block)), lens), device=eng.device)
+            c_idx = torch.as_tensor(np.concatenate([self.excl_row(v) for v in block]).astype(np.int64), device=eng.device)
+            keep[r_idx, c_idx] = False
+        def to_host(t):
+            # page-locked destination: three copies of ~100 KB per user are what this path costs, pageable memory
+            # moves them at a fifth of the link rate; the arrays handed out below are views of these buffers
+            h = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+            h.copy_(t, non_blocking=True)
+            return h
+        cand_t = to_host(keep.nonzero()[:, 1])                               # int64, row-major: per user ascending
+        sdt = getattr(m, "score_dtype", np.float32)
+        scores_t = to_host(dense[keep] if sdt == np.float32 else dense[keep].to(torch.float64))
+        ranked_t = to_host(ranked.to(torch.int64))
+        n_h = n_cand.cpu().numpy().astype(np.int64)
+        torch.cuda.synchronize(eng.device)
+        cand_h, scores_h, ranked_h = cand_t.numpy(), scores_t.numpy(), ranked_t.numpy()
+        off = np.concatenate([[0], np.cumsum(n_h)])
+        for i, v in enumerate(block):
+            caches[0][v] = ranked_h[i, : n_h[i]]
+            caches[1][v] = scores_h[off[i]: off[i + 1]]
+            caches[2][v] = cand_h[off[i]: off[i + 1]]
+        return caches[0]._explicit[u], caches[1]._explicit[u]
 
 
 def cache_rankings(model, user_idx, item_indices, k=-1):
@@ -221,7 +384,7 @@ def export_candidate_pools(model, pool_size, batch_users=1 << 16, _engine=None):
         from_full(int(u))
     if len(lazy):
         eng.set_catalogue_items(owner.n_items)
-        excl = owner.excl
+        excl = owner.excl_global()
         eng.set_exclusion_csr(excl.indptr.astype(np.int64), excl.indices.astype(np.int32))
         k = min(pool_size, eng.n_items)
         for lo in range(0, len(lazy), int(batch_users)):
@@ -255,7 +418,7 @@ def plan_metrics(metrics, max_fused_k=MAX_FUSED_K):
     return specs, ks, need_auc, need_list
 
 
-def _append_unknown_items(ids, users, excl, n_known, n_items):
+def _append_unknown_items(ids, users, excl, n_known, n_items, row0=0):
     """Top-K lists of users with fewer than K known candidates continue with the unknown items
     [n_known, n_items) that are not excluded, in ascending index (host bookkeeping: their order does
     not depend on any score)."""
@@ -264,8 +427,8 @@ def _append_unknown_items(ids, users, excl, n_known, n_items):
         return ids
     host = ids[short].cpu().numpy()
     for r, row in zip(short, host):
-        u = int(users[r])
-        ex = excl[u].indices if u < excl.shape[0] else np.zeros(0, np.int64)
+        u = int(users[r]) - row0
+        ex = excl[u].indices if 0 <= u < excl.shape[0] else np.zeros(0, np.int64)
         free = np.setdiff1d(np.arange(n_known, n_items), ex[ex >= n_known])
         k0 = int((row >= 0).sum())
         take = free[: len(row) - k0]
@@ -279,11 +442,17 @@ def _append_unknown_items(ids, users, excl, n_known, n_items):
 def ranking_eval(model, metrics, train_set, test_set, val_set=None, rating_threshold=1.0, exclude_unknowns=True,
                  verbose=False, *, batch_pairs=None, distributed="auto", gather_user_results=True, _engine=None):
     """Evaluate `model` on ranking metrics: reference signature and return value
-    (base_method.py:185-305).  Keyword-only extras: `batch_pairs` bounds users x items of a dense
+    (base_method.py:185-305); `user_results[i]` is a `UserResults` mapping (reads and pickles like the reference's
+    dict).  Keyword-only extras: `batch_pairs` bounds users x items of a dense
     score batch (AUC / k = -1 paths; default 2^32 -- a 16 GB buffer -- and 2^28 where full sorted lists are
     built), `distributed` shards the test users over the ranks of an
     initialised torch.distributed group and all-reduces the metric sums (one RCCL/gloo
-    all-reduce), `gather_user_results` also gathers the per-user values to every rank."""
+    all-reduce), `gather_user_results` also gathers the per-user values to every rank.
+
+    Sharded runs (world > 1): a rank builds and uploads only ITS users' rows -- the exclusion / truth CSRs of the
+    user range [r0, r1) it evaluates and an engine that holds only those rows of the user-side parameters
+    (`model._hip_engine(rows=(r0, r1))`); item-side parameters are replicated.
+    `_engine` (tests) is an engine, or a callable (r0, r1) -> engine over those user rows."""
     if len(metrics) == 0:
         return [], []
     import torch
@@ -293,38 +462,58 @@ def ranking_eval(model, metrics, train_set, test_set, val_set=None, rating_thres
     if _engine is None and not hasattr(model, "_hip_engine"):
         raise TypeError("ranking_eval needs a model with the HIP scoring path (recommenders_amd.models.HipScoringMixin); "
                         "there is no CPU fallback")
-    eng = model._hip_engine() if _engine is None else _engine
-    specs, ks, need_auc, need_list = plan_metrics(
-        metrics, eng.max_fused_topk() if hasattr(eng, "max_fused_topk") else MAX_FUSED_K_ITEM)
 
     n_items = train_set.num_items if exclude_unknowns else test_set.num_items
+    # users with a stored test entry = np.unique(test_set.uir_tuple[0]) (base_method.py:254), read off the CSR rows
+    test_mat = test_set.csr_matrix
+    test_users = np.flatnonzero(np.diff(sp.csr_matrix(test_mat).indptr)).astype(np.int64)
+    n_rows = int(test_users.max()) + 1 if len(test_users) else 0
+    has_pos = cached_users_with_positives(test_mat, rating_threshold, n_rows)
+    users = test_users[has_pos[test_users]]                      # base_method.py:258-259
+
+    # ---- shard users over ranks: contiguous ranges of the evaluated users, and only their rows of everything
+    world, rank = ifr_dist.world_and_rank(distributed)
+    lo, hi = ifr_dist.shard_range(len(users), rank, world)
+    my_users = users[lo:hi]
+    sharded = world > 1 and (_engine is None or callable(_engine))
+    if sharded:
+        r0, r1 = (int(my_users[0]), int(my_users[-1]) + 1) if len(my_users) else (0, 0)
+    else:
+        r0, r1 = 0, n_rows
+    if _engine is None:
+        eng = model._hip_engine(rows=(r0, r1)) if sharded else model._hip_engine()
+    else:
+        eng = _engine(r0, r1) if callable(_engine) else _engine
+    row0 = int(getattr(eng, "row0", 0)) if sharded else 0
+    if sharded and row0 != r0:
+        if row0 != 0:
+            raise RuntimeError(f"the engine for user rows [{r0}, {r1}) starts at row {row0}")
+        sharded, r0, r1 = False, 0, n_rows           # the model only has an engine over all users: index it with their own rows
+    specs, ks, need_auc, need_list = plan_metrics(
+        metrics, eng.max_fused_topk() if hasattr(eng, "max_fused_topk") else MAX_FUSED_K_ITEM)
     if n_items < eng.n_items:
         raise ValueError(f"ranking over {n_items} items but the model scores {eng.n_items}")
     # n_items > eng.n_items: exclude_unknowns=False with items the model has never seen.  They score the
     # user's minimum (recommender.py:631-635), i.e. they tie at the bottom and, having the largest
     # indices, rank after every known candidate.
     eng.set_catalogue_items(n_items)
-    # users with a stored test entry = np.unique(test_set.uir_tuple[0]) (base_method.py:254), read off the CSR rows
-    test_users = np.flatnonzero(np.diff(sp.csr_matrix(test_set.csr_matrix).indptr)).astype(np.int64)
-    n_rows = int(test_users.max()) + 1 if len(test_users) else 0
-    truth, excl, has_pos = cached_eval_csrs(train_set.csr_matrix, test_set.csr_matrix,
-                                            None if val_set is None else val_set.csr_matrix,
-                                            rating_threshold, n_items, n_rows)
+    truth, excl, _ = cached_eval_csrs(train_set.csr_matrix, test_mat, None if val_set is None else val_set.csr_matrix,
+                                      rating_threshold, n_items, r1 - r0, r0)
     # reference quirk kept: users already in the model's caches are NOT re-ranked
     # (base_method.py:166-167), so their earlier candidate set (exclusion rows) stays in force
     prev = getattr(model, "_hip_cache_owner", None)
     if prev is not None and prev.excl is excl:
         pass                                                     # same splits as last time: the rows are identical
-    elif prev is not None and prev.n_items == n_items and len(prev.users):
-        reuse = prev.users[prev.users < n_rows]
+    elif prev is not None and prev.n_items == n_items and prev.row0 == r0 and len(prev.users):
+        n_loc = r1 - r0
+        reuse = prev.users[(prev.users >= r0) & (prev.users < r1)] - r0
         if len(reuse):
-            keep = np.ones(n_rows, bool)
+            keep = np.ones(n_loc, bool)
             keep[reuse] = False
-            old = prev.excl[:n_rows] if prev.excl.shape[0] >= n_rows else sp.vstack(
-                [prev.excl, sp.csr_matrix((n_rows - prev.excl.shape[0], n_items), dtype=prev.excl.dtype)]).tocsr()
+            old = prev.excl[:n_loc] if prev.excl.shape[0] >= n_loc else sp.vstack(
+                [prev.excl, sp.csr_matrix((n_loc - prev.excl.shape[0], n_items), dtype=prev.excl.dtype)]).tocsr()
             excl = (sp.diags(keep.astype(np.int8)) @ excl + sp.diags((~keep).astype(np.int8)) @ old).tocsr()
             excl.sort_indices()
-    users = test_users[has_pos[test_users]]                      # base_method.py:258-259
     # the memoised CSRs are uploaded once per engine: a repeated evaluation on the same splits finds them in place
     if getattr(eng, "exclusion_source", None) is not excl:
         eng.set_exclusion_csr(excl.indptr.astype(np.int64), excl.indices.astype(np.int32))
@@ -333,21 +522,18 @@ def ranking_eval(model, metrics, train_set, test_set, val_set=None, rating_thres
         eng.set_truth_csr(truth.indptr.astype(np.int64), truth.indices.astype(np.int32))
         eng.truth_source = truth
 
-    # ---- shard users over ranks
-    world, rank = ifr_dist.world_and_rank(distributed)
-    lo, hi = ifr_dist.shard_range(len(users), rank, world)
-    my_users = users[lo:hi]
     # Users the model does not know keep their own index: the engine holds an all-zero factor row
     # for each of them (HipScoringMixin._hip_engine), which reproduces both "the user term is
     # dropped" (MF, recom_mf.py:277-280) and "constant default score, every candidate ties"
     # (ScoreException, recommender.py:626-627: same order, same metrics).
-    if len(my_users) and int(my_users.max()) >= eng.n_users:
+    loc_users = my_users - row0                                  # the engine's (and the CSRs') row of every user
+    if len(loc_users) and int(loc_users.max()) >= eng.n_users:
         raise ValueError(f"test user index {int(my_users.max())} beyond the {eng.n_users} rows the engine holds")
     n = len(my_users)
     values = np.full((n, len(specs)), np.nan)
     col_of = {}
     if n:
-        dev_users = torch.as_tensor(my_users.astype(np.int32), device=eng.device)
+        dev_users = torch.as_tensor(loc_users.astype(np.int32), device=eng.device)
         # top-K cut-offs and AUC together: the fused kernel also writes the score rows AUC reads (one GEMM, not two)
         fused_dense = bool(not need_list and ks and need_auc and hasattr(eng, "can_rank_topk_dense")
                            and eng.can_rank_topk_dense(max(ks)))
@@ -368,7 +554,7 @@ def ranking_eval(model, metrics, train_set, test_set, val_set=None, rating_thres
             else:
                 ids, _ = eng.rank_topk(dev_users, kmax)
             if n_items > eng.n_items:
-                ids = _append_unknown_items(ids, my_users, excl, eng.n_items, n_items)
+                ids = _append_unknown_items(ids, my_users, excl, eng.n_items, n_items, row0)
             per_user, _, _ = eng.eval_topk_metrics(dev_users, ids, ks)
             per_user = per_user.cpu().numpy()
             for qi, k in enumerate(ks):
@@ -431,12 +617,12 @@ def ranking_eval(model, metrics, train_set, test_set, val_set=None, rating_thres
     all_users, all_values = my_users, values
     if world > 1 and gather_user_results:
         all_users, all_values = ifr_dist.gather_rows(my_users, values, world)
-    user_results = [dict(zip(all_users.tolist(), all_values[:, i].tolist())) for i in range(len(specs))]
+    user_results = [UserResults(all_users, all_values[:, i]) for i in range(len(specs))]
 
     # ---- result caches: lazy, same candidate sets as this evaluation
     if hasattr(model, "rank"):
-        old_users = prev.users if prev is not None else np.zeros(0, np.int64)
-        owner = _CacheOwner(model, excl, n_items, np.union1d(old_users, users))
+        old_users = prev.users if (prev is not None and prev.row0 == r0) else np.zeros(0, np.int64)
+        owner = _CacheOwner(model, excl, n_items, np.union1d(old_users, my_users), r0)
         model._hip_cache_owner = owner
         for field in ("ranked_items", "item_scores", "item_scores_mapped_indices"):
             cur = getattr(model, field, {})

@@ -148,33 +148,64 @@ class HipScoringMixin:
     score_dtype = np.float32
 
     # ---- engine life cycle
-    def _hip_engine(self):
+    def _hip_engine(self, rows=None):
+        """The engine that holds the whole model, or -- rows=(r0, r1), a rank of a sharded evaluation -- one that holds
+        only the user rows [r0, r1) of the user-side parameters (engine row i = user r0 + i, `eng.row0` = r0); the
+        item side is replicated.  The last shard engine is kept."""
+        if rows is not None:
+            r0, r1 = int(rows[0]), int(rows[1])
+            shard = getattr(self, "_hip_shard", None)
+            if shard is not None and shard[0] == (r0, r1):
+                return shard[1]
+            if shard is not None:
+                shard[1].close()
+            from .engine import HipScorer
+            eng = HipScorer(self.hip_device)
+            try:
+                self._hip_setup(eng, (r0, r1))
+            except RuntimeError:
+                # a model that was built on the device keeps its parameters in the full engine only: use that one
+                # (row0 = 0; ranking_eval then indexes it with the users' own rows)
+                eng.close()
+                self._hip_shard = None
+                return self._hip_engine()
+            eng.row0 = r0
+            self._hip_shard = ((r0, r1), eng)
+            return eng
         eng = getattr(self, "_hip", None)
         if eng is None:
             from .engine import HipScorer
             eng = HipScorer(self.hip_device)
             self._hip_setup(eng)
+            eng.row0 = 0
             self._hip = eng
         return eng
 
-    def _hip_setup(self, eng):
-        """Upload the model to a fresh engine (dot-product models; item-item models override)."""
+    def _hip_setup(self, eng, rows=None):
+        """Upload the model to a fresh engine (dot-product models; item-item models override).  rows=(r0, r1): only
+        those user rows."""
         U, V, ubase, ibase = self._hip_factor_params()
-        U = np.ascontiguousarray(U, np.float32)
         # all-zero rows for every user index the model has no factors for (up to total_users)
         # plus one spare: users whose user term is dropped, or who cannot be scored, map there
         n_ext = max(int(self.total_users or 0), U.shape[0]) + 1
-        Ue = np.zeros((n_ext, U.shape[1]), np.float32)
-        Ue[: U.shape[0]] = U
+        r0, r1 = (0, n_ext) if rows is None else (int(rows[0]), int(rows[1]))
+        n_loc = max(r1 - r0, 1)
+        have = max(0, min(r1, U.shape[0]) - r0)                   # rows of the range the model has factors for
+        Ue = np.zeros((n_loc, U.shape[1]), np.float32)
+        if have:
+            Ue[:have] = np.asarray(U[r0:r0 + have], np.float32)
         ube = None
         if ubase is not None:
-            ube = np.zeros(n_ext, np.float32)
-            ube[: len(ubase)] = np.asarray(ubase, np.float32)
+            ube = np.zeros(n_loc, np.float32)
+            hb = max(0, min(r1, len(ubase)) - r0)
+            if hb:
+                ube[:hb] = np.asarray(ubase[r0:r0 + hb], np.float32)
         if ube is None and ibase is not None:
-            ube = np.zeros(len(Ue), np.float32)
+            ube = np.zeros(n_loc, np.float32)
         eng.set_factors(Ue, np.ascontiguousarray(V, np.float32), ube,
                         None if ibase is None else np.ascontiguousarray(ibase, np.float32))
-        self._hip_zero_row = n_ext - 1
+        if rows is None:
+            self._hip_zero_row = n_ext - 1
 
     def hip_invalidate(self):
         """Drop the device copy (call after the parameters change)."""
@@ -182,6 +213,10 @@ class HipScoringMixin:
         if eng is not None:
             eng.close()
         self._hip = None
+        shard = getattr(self, "_hip_shard", None)
+        if shard is not None:
+            shard[1].close()
+        self._hip_shard = None
 
     # ---- Recommender.score
     def score(self, user_idx, item_idx=None, **kwargs):
@@ -368,9 +403,13 @@ class ItemItemScoringMixin(HipScoringMixin):
 
     score_dtype = np.float64
 
-    def _hip_setup(self, eng):
+    def _hip_setup(self, eng, rows=None):
         import scipy.sparse as sp
         M, hist, col_scale = self._hip_item_model()
+        if rows is not None:                                        # a shard: the histories of its users only
+            hist = sp.csr_matrix(hist)
+            r0, r1 = int(rows[0]), int(rows[1])
+            hist = hist[min(r0, hist.shape[0]):min(r1, hist.shape[0])]
         if sp.issparse(M):
             M = sp.csr_matrix(M)
             M.sort_indices()
@@ -378,13 +417,14 @@ class ItemItemScoringMixin(HipScoringMixin):
                                     M.data.astype(np.float32), M.shape[0], col_scale)
         else:
             eng.set_item_matrix_dense(M, col_scale)
-        self._hip_set_histories(eng, hist)
+        self._hip_set_histories(eng, hist, shard=rows is not None)
 
-    def _hip_set_histories(self, eng, hist):
+    def _hip_set_histories(self, eng, hist, shard=False):
         import scipy.sparse as sp
         hist = sp.csr_matrix(hist)
         eng.set_history_csr(hist.indptr.astype(np.int64), hist.indices.astype(np.int32), hist.data.astype(np.float32))
-        self._hip_zero_row = max(int(self.total_users or 0), hist.shape[0])     # a user without history
+        if not shard:
+            self._hip_zero_row = max(int(self.total_users or 0), hist.shape[0])     # a user without history
 
     def _hip_user_row(self, user_idx):
         return int(user_idx) if self.knows_user(user_idx) else -1

@@ -33,17 +33,34 @@ def _worker(rank, world, port, out_dir):
     from test_host_logic import _datasets, _engine
     d = load_golden("toy_all_models.npz")
     train_set, test_set, val_set = _datasets(d)
-    eng = _engine(d, "bpr", test_set.num_users)
+    full = _engine(d, "bpr", test_set.num_users)
+    made = []
+
+    def shard_engine(r0, r1):
+        """What model._hip_engine(rows=(r0, r1)) does on a GPU: an engine that holds only those user rows."""
+        from fake_engine import OracleEngine
+        eng = OracleEngine(full.U[r0:r1], full.V, None if full.ubase is None else full.ubase[r0:r1], full.ibase)
+        eng.row0 = r0
+        made.append(eng)
+        return eng
+
     fake = types.SimpleNamespace(is_fitted=True)
     mets = [M.NDCG(k=10), M.Recall(k=10), M.AUC()]
     avg, per = ifr_eval.ranking_eval(fake, mets, train_set, test_set, val_set,
-                                     rating_threshold=float(d["rating_threshold"]), _engine=eng, distributed=True)
+                                     rating_threshold=float(d["rating_threshold"]), _engine=shard_engine, distributed=True)
     avg_local, per_local = ifr_eval.ranking_eval(fake, mets, train_set, test_set, val_set,
-                                                 rating_threshold=float(d["rating_threshold"]), _engine=eng,
+                                                 rating_threshold=float(d["rating_threshold"]), _engine=shard_engine,
                                                  distributed=True, gather_user_results=False)
+    mine = sorted(per_local[0].keys())
+    eng = made[-1]
+    # the rank's engine saw only its own rows: user factors, exclusion rows and truth rows of [first user, last user]
+    span = mine[-1] - mine[0] + 1
+    assert eng.row0 == mine[0] and eng.n_users == span
+    assert len(eng.ex[0]) - 1 == span and len(eng.tr[0]) - 1 == span
     np.savez(os.path.join(out_dir, f"r{rank}.npz"), avg=np.asarray(avg), users=np.asarray(sorted(per[0].keys())),
              ndcg=np.asarray([per[0][u] for u in sorted(per[0].keys())]), avg_local=np.asarray(avg_local),
-             n_local=len(per_local[0]))
+             n_local=len(per_local[0]), first=mine[0], last=mine[-1], rows=eng.n_users,
+             total_rows=test_set.num_users)
     dist.destroy_process_group()
 
 
@@ -66,3 +83,6 @@ def test_two_rank_sharded_eval_matches_single_process(tmp_path, toy):
     np.testing.assert_array_equal(r0["users"], sorted(per[0].keys()))       # gathered per-user values are complete
     np.testing.assert_allclose(r0["ndcg"], [per[0][u] for u in sorted(per[0].keys())], atol=0)
     assert int(r0["n_local"]) + int(r1["n_local"]) == len(per[0]) and abs(int(r0["n_local"]) - int(r1["n_local"])) <= 1
+    # each rank held only its own user rows: two disjoint ranges, neither the whole user set
+    assert int(r0["last"]) < int(r1["first"])
+    assert int(r0["rows"]) + int(r1["rows"]) <= int(r0["total_rows"]) and int(r0["rows"]) < int(r0["total_rows"])

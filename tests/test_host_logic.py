@@ -409,3 +409,18 @@ def test_dense_row_batches_reuse_one_buffer_when_memory_is_short(toy):
     # the sorted-list branch keeps 28 bytes per (row, item): the same memory holds a quarter... one row here
     assert ifr_eval._rows_that_fit(eng, 1000, 28 * n_items) == 1
     assert ifr_eval._rows_that_fit(eng, 3, 4 * n_items) == 3
+
+
+def test_user_results_reads_and_pickles_like_the_reference_dict():
+    import pickle
+    from recommenders_amd import UserResults
+    r = UserResults([7, 2, 5], [0.7, 0.2, 0.5])                     # any order in, ascending inside
+    assert list(r) == [2, 5, 7] and len(r) == 3 and 5 in r and 4 not in r
+    assert r[7] == 0.7 and r == {2: 0.2, 5: 0.5, 7: 0.7} and r.keys() == [2, 5, 7]
+    assert sum(r.values()) / len(r) == pytest.approx(1.4 / 3)       # the reference's aggregation (base_method.py:302-303)
+    assert dict(r.items()) == r.to_dict()
+    with pytest.raises(KeyError):
+        r[3]
+    back = pickle.loads(pickle.dumps(r))
+    assert type(back) is dict and back == r.to_dict()
+    assert r == pytest.approx({2: 0.2, 5: 0.5, 7: 0.7 + 1e-15})

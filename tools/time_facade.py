@@ -32,3 +32,12 @@ for name, ms in [("list metrics [NDCG(-1), Recall(100), MRR, MAP]", [M.NDCG(k=-1
         torch.cuda.synchronize()
         dt = time.perf_counter() - t
     print(f"{name}: {dt:.3f} s  {nu/dt/1e6:.2f} M users/s  avg {[round(a, 6) for a in avg]}", flush=True)
+# per-user access to the lazy result caches (block materialisation)
+avg, _ = ranking_eval(model, mets, train_set, test_set, verbose=False)
+us = list(model.ranked_items.keys())[:8192]
+t = time.perf_counter()
+tot = 0
+for u in us:
+    tot += len(model.ranked_items[u]) + len(model.item_scores[u]) + len(model.item_scores_mapped_indices[u])
+dt = time.perf_counter() - t
+print(f"lazy caches: {len(us)} users read in {dt:.3f} s = {1e6 * dt / len(us):.1f} us per user ({tot} entries)", flush=True)
