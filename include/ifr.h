@@ -88,6 +88,15 @@ int ifr_set_item_matrix_dense(ifr_handle h, const float *M, int64_t n_items, int
 int ifr_set_item_matrix_csr(ifr_handle h, const int64_t *indptr, const int32_t *indices, const float *values,
                             int64_t n_items, int64_t nnz, const float *col_scale);
 
+/* The fp64 option of the dense item matrix (the reference scores EASE in float64: B from np.linalg.inv on float64,
+ * recom_ease.py:78-95, score X[u, :].dot(B), :123-124): M [n_items][ld] row-major fp64 is kept in fp64 on the device and
+ * every (user, item) sum is one fp64 fma chain over the history row in CSR order, times col_scale in fp64.
+ * ifr_score_dense_f64 returns those sums; ifr_rank_topk, ifr_score_dense and everything downstream round them once
+ * to fp32 and rank that.  Twice the bytes of the fp32 matrix per user (the path is HBM-bound). */
+int ifr_set_item_matrix_dense_f64(ifr_handle h, const double *M, int64_t n_items, int64_t ld, const float *col_scale);
+/* out: dev [n][ld] fp64, ld >= n_items; IFR_ERR_STATE unless the item matrix is an fp64 one. */
+int ifr_score_dense_f64(ifr_handle h, const int32_t *user_ids, int64_t n, double *out, int64_t ld, void *stream);
+
 /* EASE model build on the device, cornac/models/ease/recom_ease.py:75-95:
  *     G = X^T X + lamb I,  P = G^-1,  B = P / (-diag P) column-wise,  diag B = 0,  posB: B[B < 0] = 0
  * X = train_set.matrix as CSR [n_users][n_items] (columns strictly ascending inside a row, finite
@@ -96,7 +105,8 @@ int ifr_set_item_matrix_csr(ifr_handle h, const int64_t *indptr, const int32_t *
  * equal to ~1e-10 relative, tests/test_gpu_fit.py).  B becomes the handle's dense item matrix exactly
  * as if it had been passed to ifr_set_item_matrix_dense (fp32, no col_scale); call ifr_set_history_csr
  * next.  B_out: host fp64 [n_items][n_items] row-major copy of B, or NULL.  Needs 16 * n_items^2 bytes
- * of device memory while it runs. */
+ * of device memory while it runs.  After ifr_set_option(h, "item_f64", 1) B is installed in fp64 instead, as if passed
+ * to ifr_set_item_matrix_dense_f64. */
 int ifr_fit_ease(ifr_handle h, const int64_t *x_indptr, const int32_t *x_indices, const float *x_values, int64_t n_users,
                  int64_t n_items, int64_t nnz, double lamb, int posB, double *B_out);
 

@@ -289,6 +289,24 @@ void orc_score_item_dense(const float *M, int64_t ld, int n_items,
     }
 }
 
+/* The fp64 option of the dense item matrix: one fp64 fma chain per column in history order, times col_scale in fp64
+ * (the reference's X[u, :].dot(B) in float64, cornac/models/ease/recom_ease.py:123-124, is a float64 sum over the same
+ * terms; its order and roundings are SciPy's, so the two agree to a few ulp, not bit for bit).  out32 (may be NULL)
+ * receives the sums rounded once to fp32: the keys the ranking uses. */
+void orc_score_item_dense_f64(const double *M, int64_t ld, int n_items,
+                              const int32_t *h_idx, const float *h_val, int n_hist,
+                              const float *col_scale, double *out, float *out32)
+{
+    for (int c = 0; c < n_items; ++c) {
+        double acc = 0.0;
+        for (int e = 0; e < n_hist; ++e)
+            acc = fma((double)h_val[e], M[(size_t)h_idx[e] * (size_t)ld + (size_t)c], acc);
+        if (col_scale) acc *= (double)col_scale[c];
+        out[c] = acc;
+        if (out32) out32[c] = (float)acc;
+    }
+}
+
 /* returns 0, or -1 if a fixed-point sum left the 62-bit range the shift must guarantee */
 int orc_score_item_csr(const int64_t *m_ptr, const int32_t *m_idx, const float *m_val, int n_items,
                        const int32_t *h_idx, const float *h_val, int n_hist,

@@ -381,6 +381,16 @@ def _f32(a):
     return None if a is None else np.ascontiguousarray(a, np.float32)
 
 
+def c_rank_topk(scores, excl, K):
+    """orc_rank_topk on one fp32 score row: (ids [K] padded with -1, scores [K] padded with -inf, candidate count)."""
+    scores, excl = _f32(scores), np.sort(_i32(excl))
+    ids = np.empty(K, np.int32)
+    sc = np.empty(K, np.float32)
+    n = c_lib().orc_rank_topk(_p(scores, ctypes.c_float), len(scores), _p(excl, ctypes.c_int32), len(excl), int(K),
+                              _p(ids, ctypes.c_int32), _p(sc, ctypes.c_float))
+    return ids, sc, n
+
+
 def c_score_item_dense(M, h_idx, h_val, col_scale=None):
     """orc_score_item_dense: fp32 fma chain over the history in order, then * col_scale."""
     M = np.ascontiguousarray(M, np.float32)
@@ -390,6 +400,19 @@ def c_score_item_dense(M, h_idx, h_val, col_scale=None):
                                  _p(h_idx, ctypes.c_int32), _p(h_val, ctypes.c_float), len(h_idx),
                                  _p(cs, ctypes.c_float), _p(out, ctypes.c_float))
     return out
+
+
+def c_score_item_dense_f64(M, h_idx, h_val, col_scale=None):
+    """orc_score_item_dense_f64: fp64 fma chain over the history in order, then * col_scale in fp64.
+    Returns (float64 scores, the same rounded once to fp32)."""
+    M = np.ascontiguousarray(M, np.float64)
+    h_idx, h_val, cs = _i32(h_idx), _f32(h_val), _f32(col_scale)
+    out = np.empty(M.shape[0], np.float64)
+    out32 = np.empty(M.shape[0], np.float32)
+    c_lib().orc_score_item_dense_f64(_p(M, ctypes.c_double), ctypes.c_int64(M.shape[1]), M.shape[0],
+                                     _p(h_idx, ctypes.c_int32), _p(h_val, ctypes.c_float), len(h_idx),
+                                     _p(cs, ctypes.c_float), _p(out, ctypes.c_double), _p(out32, ctypes.c_float))
+    return out, out32
 
 
 def c_score_item_csr(m_ptr, m_idx, m_val, n_items, h_idx, h_val, shift, col_scale=None):

@@ -64,6 +64,8 @@ struct ifr_handle_s {
     int mode = MODE_NONE;
     // item-item model: dense M or chunk-blocked CSR, column scale, user histories
     float *iiM = nullptr; int64_t ii_ld = 0;
+    double *iiM64 = nullptr;     // dense item matrix of the fp64 scoring option (then iiM is null)
+    int opt_item_f64 = 0;        // ifr_fit_ease installs B in fp64
     int64_t *ii_cptr = nullptr; int32_t *ii_idx = nullptr; float *ii_val = nullptr; int64_t ii_nnz = 0;
     float *ii_pen = nullptr;
     int ii_chunks = 0;
@@ -209,7 +211,7 @@ int64_t catalogue_items(ifr_handle h) { return h->opt_catalogue > h->n_items ? h
 
 void clear_item_model(ifr_handle h)
 {
-    dfree(h->iiM); dfree(h->ii_cptr); dfree(h->ii_idx); dfree(h->ii_val); dfree(h->ii_pen);
+    dfree(h->iiM); dfree(h->iiM64); dfree(h->ii_cptr); dfree(h->ii_idx); dfree(h->ii_val); dfree(h->ii_pen);
     dfree(h->hs_ptr); dfree(h->hs_idx); dfree(h->hs_val);
     h->ii_ld = 0; h->ii_nnz = 0; h->ii_chunks = 0; h->ii_maxabs = 0.f;
     h->hs_rows = 0; h->hs_nnz = 0; h->hs_l1max = 0.f;
@@ -299,7 +301,7 @@ int ifr_destroy(ifr_handle h)
     dfree(h->U); dfree(h->V); dfree(h->ibase); dfree(h->ubase);
     dfree(h->ex_ptr); dfree(h->ex_idx); dfree(h->ex_cnt); dfree(h->ex_pair);
     dfree(h->tr_ptr); dfree(h->tr_idx); dfree(h->discount);
-    dfree(h->iiM); dfree(h->ii_cptr); dfree(h->ii_idx); dfree(h->ii_val); dfree(h->ii_pen);
+    dfree(h->iiM); dfree(h->iiM64); dfree(h->ii_cptr); dfree(h->ii_idx); dfree(h->ii_val); dfree(h->ii_pen);
     dfree(h->hs_ptr); dfree(h->hs_idx); dfree(h->hs_val);
     dfree(h->ws_part); dfree(h->ws_met); dfree(h->ws_sort);
     ifr::ease_release(&h->rocblas);
@@ -318,6 +320,7 @@ int ifr_set_option(ifr_handle h, const char *name, int64_t value)
     if (!strcmp(name, "chunks")) h->opt_chunks = (int)value;
     else if (!strcmp(name, "share_bounds")) h->opt_share_bounds = (int)value;
     else if (!strcmp(name, "tail_split")) h->opt_tail_split = (int)value;
+    else if (!strcmp(name, "item_f64")) h->opt_item_f64 = value != 0;
     else if (!strcmp(name, "wide_stats")) h->opt_wide_stats = (int)value;
     else if (!strcmp(name, "wide_chunk_cap")) h->opt_wide_chunk_cap = (int)std::max<int64_t>(1, value);
     else if (!strcmp(name, "debug_mode")) h->opt_debug = (int)value;
@@ -470,6 +473,31 @@ int ifr_set_item_matrix_dense(ifr_handle h, const float *M, int64_t n_items, int
     return IFR_OK;
 }
 
+int ifr_set_item_matrix_dense_f64(ifr_handle h, const double *M, int64_t n_items, int64_t ld, const float *col_scale)
+{
+    if (!h) return IFR_ERR_ARG;
+    if (!M || n_items <= 0 || ld < n_items) return fail(h, IFR_ERR_ARG, "ifr_set_item_matrix_dense_f64: null/empty input or ld < n_items");
+    if (n_items > (int64_t)1 << 30) return fail(h, IFR_ERR_ARG, "ifr_set_item_matrix_dense_f64: n_items too large");
+    IFR_HIP(h, hipSetDevice(h->device));
+    const int64_t old_items = h->n_items;
+    clear_factor_model(h);
+    clear_item_model(h);
+    h->n_items = old_items;
+    drop_csrs_if_catalogue_changes(h, n_items);
+    h->n_items = 0;
+    const int chunk = ifr::item_item_chunk_f64(), pass = ifr::item_item_pass();
+    const int64_t ldm = (n_items + pass - 1) / pass * pass;
+    IFR_HIP(h, hipMalloc((void **)&h->iiM64, sizeof(double) * n_items * ldm));
+    if (ldm != n_items) IFR_HIP(h, hipMemset(h->iiM64, 0, sizeof(double) * n_items * ldm));
+    IFR_HIP(h, hipMemcpy2D(h->iiM64, sizeof(double) * ldm, M, sizeof(double) * ld, sizeof(double) * n_items, n_items, hipMemcpyDefault));
+    h->ii_ld = ldm;
+    h->ii_chunks = (int)((n_items + chunk - 1) / chunk);
+    int rc = set_col_scale(h, col_scale, n_items, (int64_t)h->ii_chunks * chunk);
+    if (rc) return rc;
+    h->n_items = n_items; h->n_users = 0; h->mode = MODE_ITEM_DENSE; h->opt_catalogue = 0;
+    return IFR_OK;
+}
+
 int ifr_fit_ease(ifr_handle h, const int64_t *x_indptr, const int32_t *x_indices, const float *x_values, int64_t n_users,
                  int64_t n_items, int64_t nnz, double lamb, int posB, double *B_out)
 {
@@ -510,15 +538,19 @@ int ifr_fit_ease(ifr_handle h, const int64_t *x_indptr, const int32_t *x_indices
                         : flags[0] ? "ifr_fit_ease: item index outside [0, n_items) or not strictly ascending inside a row"
                                    : "ifr_fit_ease: non-finite rating");
     }
-    const int chunk = ifr::item_item_chunk(false), pass = ifr::item_item_pass();
+    const bool f64 = h->opt_item_f64 != 0;         // option "item_f64": B stays fp64 and is scored in fp64
+    const int chunk = f64 ? ifr::item_item_chunk_f64() : ifr::item_item_chunk(false), pass = ifr::item_item_pass();
     const int64_t ldm = (n_items + pass - 1) / pass * pass;
-    if (hipMalloc((void **)&h->iiM, sizeof(float) * n_items * ldm) != hipSuccess ||
-        hipMemset(h->iiM, 0, sizeof(float) * n_items * ldm) != hipSuccess) {
+    const size_t m_bytes = (f64 ? sizeof(double) : sizeof(float)) * (size_t)n_items * (size_t)ldm;
+    void *m_dev = nullptr;
+    if (hipMalloc(&m_dev, m_bytes) != hipSuccess || hipMemset(m_dev, 0, m_bytes) != hipSuccess) {
+        if (m_dev) (void)hipFree(m_dev);
         cleanup(); clear_item_model(h);
         return fail(h, IFR_ERR_HIP, "ifr_fit_ease: device memory for B");
     }
+    if (f64) h->iiM64 = (double *)m_dev; else h->iiM = (float *)m_dev;
     char msg[256] = "";
-    if (ifr::ease_build(d_ptr, d_idx, d_val, n_users, n_items, lamb, posB, h->iiM, ldm, B_out, &h->rocblas, msg, sizeof(msg))) {
+    if (ifr::ease_build(d_ptr, d_idx, d_val, n_users, n_items, lamb, posB, h->iiM, h->iiM64, ldm, B_out, &h->rocblas, msg, sizeof(msg))) {
         cleanup(); clear_item_model(h);
         return fail(h, IFR_ERR_HIP, msg);
     }
@@ -694,7 +726,7 @@ static int item_item_params(ifr_handle h, const int32_t *user_ids, int64_t n, if
 {
     if (!h->hs_ptr) return fail(h, IFR_ERR_STATE, "item-item model: histories not set (ifr_set_history_csr)");
     memset(p, 0, sizeof(*p));
-    p->M = h->iiM; p->ldm = h->ii_ld;
+    p->M = h->iiM; p->M64 = h->iiM64; p->ldm = h->ii_ld;
     p->cptr = h->ii_cptr; p->m_idx = h->ii_idx; p->m_val = h->ii_val; p->m_nnz = h->ii_nnz;
     p->fx_shift = h->mode == MODE_ITEM_CSR ? fixed_point_shift(h) : 0;
     p->dbg = h->opt_debug;
@@ -1159,6 +1191,23 @@ int ifr_score_dense(ifr_handle h, const int32_t *user_ids, int64_t n, float *out
     else if (h->KD == 224) launch_dense<224>(h->has_base, p, (int)grid, s);
     else launch_dense<256>(h->has_base, p, (int)grid, s);
     IFR_HIP(h, hipGetLastError());
+    return IFR_OK;
+}
+
+int ifr_score_dense_f64(ifr_handle h, const int32_t *user_ids, int64_t n, double *out, int64_t ld, void *stream)
+{
+    if (!h) return IFR_ERR_ARG;
+    if (h->mode != MODE_ITEM_DENSE || !h->iiM64)
+        return fail(h, IFR_ERR_STATE, "ifr_score_dense_f64: needs an fp64 dense item matrix (ifr_set_item_matrix_dense_f64, or ifr_fit_ease with option item_f64)");
+    if (n == 0) return IFR_OK;
+    if (!user_ids || !out || n < 0 || ld < h->n_items) return fail(h, IFR_ERR_ARG, "ifr_score_dense_f64: null argument or ld < n_items");
+    if (n > (int64_t)1 << 24) return fail(h, IFR_ERR_ARG, "ifr_score_dense_f64: more than 2^24 users in one call");
+    IFR_HIP(h, hipSetDevice(h->device));
+    ifr::ItemItemParams ip;
+    int rc = item_item_params(h, user_ids, n, &ip);
+    if (rc) return rc;
+    ip.out64 = out; ip.ld = ld;
+    if (ifr::launch_item_item(ip, false, false, (hipStream_t)stream)) return fail(h, IFR_ERR_HIP, "ifr_score_dense_f64: launch failed");
     return IFR_OK;
 }
 

@@ -5,10 +5,11 @@
 
 namespace ifr {
 
-// EASE: d_ptr/d_idx/d_val = X (device CSR, columns strictly ascending); M [n_items][ldm] fp32 (device) receives B;
-// B_host (fp64 [n_items][n_items], may be null) a copy.  rocblas_cache keeps the library handle between calls.
+// EASE: d_ptr/d_idx/d_val = X (device CSR, columns strictly ascending); M [n_items][ldm] fp32 (device) receives B -- or,
+// when M64 is not null, M64 [n_items][ldm] receives it in fp64; B_host (fp64 [n_items][n_items], may be null) a copy.
+// rocblas_cache keeps the library handle between calls.
 int ease_build(const int64_t *d_ptr, const int32_t *d_idx, const float *d_val, int64_t n_users, int64_t n_items, double lamb,
-               int posB, float *M, int64_t ldm, double *B_host, void **rocblas_cache, char *err, size_t errlen);
+               int posB, float *M, double *M64, int64_t ldm, double *B_host, void **rocblas_cache, char *err, size_t errlen);
 void ease_release(void **rocblas_cache);
 
 // RP3-beta item-item form from the binarised train matrix A (device CSR, columns strictly ascending).

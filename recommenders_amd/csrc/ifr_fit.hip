@@ -69,7 +69,9 @@ __global__ void take_diag_kernel(const double *S, int64_t n, double *d)
 
 // B[j][c] = P[j][c] / (-P[c][c]), zero diagonal, optional clamp; S is overwritten with B (fp64, for the
 // caller's copy) and M [n][ldm] receives the fp32 matrix
-__global__ __launch_bounds__(FIT_BLOCK) void ease_scale_kernel(double *S, const double *d, int64_t n, int posB, float *M, int64_t ldm)
+// (M64 != null: the fp64 matrix [n][ldm] of the fp64 scoring option instead)
+__global__ __launch_bounds__(FIT_BLOCK) void ease_scale_kernel(double *S, const double *d, int64_t n, int posB, float *M, double *M64,
+                                                               int64_t ldm)
 {
     const int64_t j = blockIdx.x;                        // grid.y is limited to 65535: rows go on x
     const int64_t c = (int64_t)blockIdx.y * FIT_BLOCK + threadIdx.x;
@@ -78,7 +80,7 @@ __global__ __launch_bounds__(FIT_BLOCK) void ease_scale_kernel(double *S, const 
     if (j == c) v = 0.0;
     if (posB && v < 0.0) v = 0.0;
     S[j * n + c] = v;
-    M[j * ldm + c] = (float)v;
+    if (M64 != nullptr) M64[j * ldm + c] = v; else M[j * ldm + c] = (float)v;
 }
 
 static int fit_fail(char *err, size_t errlen, const char *what, int code)
@@ -88,7 +90,7 @@ static int fit_fail(char *err, size_t errlen, const char *what, int code)
 }
 
 int ease_build(const int64_t *d_ptr, const int32_t *d_idx, const float *d_val, int64_t n_users, int64_t n_items, double lamb,
-               int posB, float *M, int64_t ldm, double *B_host, void **rocblas_cache, char *err, size_t errlen)
+               int posB, float *M, double *M64, int64_t ldm, double *B_host, void **rocblas_cache, char *err, size_t errlen)
 {
     const int64_t n = n_items;
     // HIP: grid.x * block.x < 2^32, grid.y <= 65535
@@ -129,7 +131,7 @@ int ease_build(const int64_t *d_ptr, const int32_t *d_idx, const float *d_val, i
     st = rocsolver_dpotrs_64(rb, rocblas_fill_upper, n, n, G, n, S, n);          // S = G^-1 (symmetric: either storage order)
     if (st != rocblas_status_success) { cleanup(); return fit_fail(err, errlen, "triangular solves failed", (int)st); }
     hipLaunchKernelGGL(take_diag_kernel, dim3(nb), dim3(256), 0, 0, S, n, diag);
-    hipLaunchKernelGGL(ease_scale_kernel, dim3((unsigned)n, nb), dim3(FIT_BLOCK), 0, 0, S, diag, n, posB, M, ldm);
+    hipLaunchKernelGGL(ease_scale_kernel, dim3((unsigned)n, nb), dim3(FIT_BLOCK), 0, 0, S, diag, n, posB, M, M64, ldm);
     e = hipGetLastError();
     if (e == hipSuccess) e = hipDeviceSynchronize();
     if (e == hipSuccess && B_host) e = hipMemcpy(B_host, S, bytes, hipMemcpyDeviceToHost);

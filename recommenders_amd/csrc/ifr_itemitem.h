@@ -7,6 +7,7 @@ namespace ifr {
 
 struct ItemItemParams {
     const float *M;              // dense: [n_items][ldm]
+    const double *M64;           // dense, fp64 option: [n_items][ldm] (then M is null)
     int64_t ldm;                 //        row stride, multiple of II_PASS
     const int64_t *cptr;         // sparse: [n_items][n_chunks + 1] entry positions per item chunk
     const int32_t *m_idx;        //         column of every entry
@@ -32,6 +33,7 @@ struct ItemItemParams {
     float *part_scores;          // [n][n_chunks][KL]   (TOPK)
     int32_t *part_ids;
     float *out;                  // [n][ld]             (dense rows)
+    double *out64;               // [n][ld]             (dense rows of the fp64 option, instead of out)
     int64_t ld;
 };
 
@@ -41,6 +43,7 @@ int item_sparse_pass_capacity();
 int item_sparse_max_chunks();
 int item_csr_pad();             // entries the CSR index / value arrays must be allocated past nnz
 int item_item_chunk(bool sparse);
+int item_item_chunk_f64();      // dense fp64 matrix: columns per workgroup
 int item_item_pass();
 int launch_validate_csr(const int64_t *ptr, const int32_t *idx, int64_t n_rows, int n_cols, int need_sorted, int *bad,
                         hipStream_t s);

@@ -33,6 +33,7 @@ constexpr int II_HIST = 512;                  // history entries staged per roun
 constexpr int II_NONE = 0x7fffffff;
 constexpr int II_DENSE_PASSES = 8;            // dense M: 8192 items per workgroup
 constexpr int II_SPARSE_PASSES = 4;           // sparse M: 4096 items per workgroup (32 KB of int64 LDS)
+constexpr int II_F64_PASSES = 4;              // dense fp64 M: 4096 items per workgroup (fp64 accumulators: twice the registers)
 constexpr int II_GROUP = 16;                  // lanes that share one sparse row segment
 constexpr int II_CSR_PAD = 64;                // entries allocated past the end of the CSR arrays (over-read, never used)
 
@@ -44,7 +45,10 @@ __device__ __forceinline__ bool ii_beats(float s, int id, float s2, int id2)
     return (s > s2) || (s == s2 && id < id2);
 }
 
-template <int PASSES, bool SPARSE, bool TOPK>
+// F64 (dense M only): M is fp64 and every (user, item) sum is one fp64 fma chain in history order, like the reference's
+// X[u, :].dot(B) in float64 (recom_ease.py:123-124); the column scale is applied in fp64, the sum is written as fp64
+// (out64) or rounded once to fp32 for the ranking epilogue.
+template <int PASSES, bool SPARSE, bool TOPK, bool F64 = false>
 __global__ __launch_bounds__(II_BLOCK, 3) void item_item_kernel(ItemItemParams p)
 {
     constexpr int CHUNK = PASSES * II_PASS;
@@ -111,6 +115,55 @@ __global__ __launch_bounds__(II_BLOCK, 3) void item_item_kernel(ItemItemParams p
             }
         }
         __syncthreads();                                 // buf is about to be rewritten as fp32 scores
+    } else if (F64) {
+        double a64[PASSES][4];
+#pragma unroll
+        for (int q = 0; q < PASSES; ++q)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) a64[q][v] = 0.0;
+        typedef double f64x2 __attribute__((ext_vector_type(2)));
+        for (int64_t base = hb; base < he; base += II_HIST) {
+            const int m = (int)min((int64_t)II_HIST, he - base);
+            __syncthreads();
+            for (int e = tid; e < m; e += II_BLOCK) { hj[e] = p.h_idx[base + e]; hx[e] = p.h_val[base + e]; }
+            __syncthreads();
+#pragma unroll 1
+            for (int e = 0; e < m; ++e) {
+                const double x = (double)hx[e];
+                const double *row = p.M64 + (int64_t)hj[e] * p.ldm + col0;
+                f64x2 r[PASSES][2];
+#pragma unroll
+                for (int q = 0; q < PASSES; ++q) {
+                    if (q < npass) {
+                        r[q][0] = *reinterpret_cast<const f64x2 *>(row + q * II_PASS);
+                        r[q][1] = *reinterpret_cast<const f64x2 *>(row + q * II_PASS + 2);
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < PASSES; ++q) {
+                    if (q < npass) {
+                        a64[q][0] = fma(x, r[q][0][0], a64[q][0]);
+                        a64[q][1] = fma(x, r[q][0][1], a64[q][1]);
+                        a64[q][2] = fma(x, r[q][1][0], a64[q][2]);
+                        a64[q][3] = fma(x, r[q][1][1], a64[q][3]);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < PASSES; ++q) {
+            if (q < npass) {
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int col = col0 + q * II_PASS + v;
+                    double s = a64[q][v];
+                    if (p.pen != nullptr) s *= (double)p.pen[col];
+                    if (!TOPK && p.out64 != nullptr && col < p.n_items) p.out64[i * p.ld + col] = s;
+                    acc[q][v] = (float)s;
+                }
+            }
+        }
+        if (!TOPK && p.out64 != nullptr) return;
     } else {
         for (int64_t base = hb; base < he; base += II_HIST) {
             const int m = (int)min((int64_t)II_HIST, he - base);
@@ -162,7 +215,7 @@ __global__ __launch_bounds__(II_BLOCK, 3) void item_item_kernel(ItemItemParams p
             }
         }
     }
-    if (p.pen != nullptr) {
+    if (p.pen != nullptr && !F64) {
 #pragma unroll
         for (int q = 0; q < PASSES; ++q) {
             if (q < npass) {
@@ -764,6 +817,12 @@ int launch_item_item(const ItemItemParams &p, bool sparse, bool topk, hipStream_
     // HIP limits grid.x * block.x to 32 bits and grid.y to 65535
     if (p.n <= 0 || p.n_chunks <= 0 || p.n > (int64_t)0xffffffffu / II_BLOCK || p.n_chunks > 65535) return -1;
     const dim3 g((unsigned)p.n, (unsigned)p.n_chunks), b(II_BLOCK);
+    if (p.M64 != nullptr) {
+        if (sparse) return -1;
+        if (topk) hipLaunchKernelGGL((item_item_kernel<II_F64_PASSES, false, true, true>), g, b, 0, stream, p);
+        else hipLaunchKernelGGL((item_item_kernel<II_F64_PASSES, false, false, true>), g, b, 0, stream, p);
+        return hipGetLastError() == hipSuccess ? 0 : -3;
+    }
     if (sparse) {
         if (topk) return -1;                             // CSR top-K is item_sparse_topk_kernel
         hipLaunchKernelGGL((item_item_kernel<II_SPARSE_PASSES, true, false>), g, b, 0, stream, p);
@@ -777,6 +836,7 @@ int launch_item_item(const ItemItemParams &p, bool sparse, bool topk, hipStream_
 int item_csr_pad() { return II_CSR_PAD; }
 int item_item_chunk(bool sparse) { return (sparse ? II_SPARSE_PASSES : II_DENSE_PASSES) * II_PASS; }
 int item_item_pass() { return II_PASS; }
+int item_item_chunk_f64() { return II_F64_PASSES * II_PASS; }
 
 // ------------------------------------------------------------------------------------
 // Set-time helpers: CSR validation, per-chunk entry positions, magnitude bounds.

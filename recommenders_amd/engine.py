@@ -142,35 +142,48 @@ class HipScorer:
         self.n_users = int(n_users)
         del ku, kub
 
-    def set_item_matrix_dense(self, M, col_scale=None):
-        """Item-item model with a dense M [I, I] (EASE's B, or a dense RP3-beta W); NumPy or torch."""
+    def set_item_matrix_dense(self, M, col_scale=None, precision="f32"):
+        """Item-item model with a dense M [I, I] (EASE's B, or a dense RP3-beta W); NumPy or torch.  precision "f64"
+        keeps M in float64 on the device: each score is a float64 sum in history order (the reference's X[u].dot(B) in
+        float64, recom_ease.py:123-124), rounded once to fp32 for ranking; score_dense_f64 returns it unrounded."""
         self.exclusion_source = self.truth_source = None    # the library drops CSRs of another catalogue size
         n_items = int(M.shape[0])
         if M.shape[1] != n_items:
             raise ValueError("the item matrix must be square")
         torch = _torch()
+        f64 = precision == "f64"
+        if precision not in ("f32", "f64"):
+            raise ValueError("precision must be 'f32' or 'f64'")
+        tdt, ndt = (torch.float64, np.float64) if f64 else (torch.float32, np.float32)
         if isinstance(M, torch.Tensor):
-            M = M if M.dtype == torch.float32 else M.float()
+            M = M if M.dtype == tdt else M.to(tdt)
             ld = M.stride(0) if M.stride(1) == 1 else None
             if ld is None:
                 M = M.contiguous()
                 ld = M.stride(0)
             pm, km = ctypes.c_void_p(M.data_ptr()), M
         else:
-            M = np.ascontiguousarray(M, np.float32)
+            M = np.ascontiguousarray(M, ndt)
             ld = n_items
             pm, km = _host_ptr(M), M
         pc, kc = self._any_ptr(col_scale, np.float32)
-        self._check(self._lib.ifr_set_item_matrix_dense(self._h, pm, n_items, int(ld), pc))
+        setter = self._lib.ifr_set_item_matrix_dense_f64 if f64 else self._lib.ifr_set_item_matrix_dense
+        self._check(setter(self._h, pm, n_items, int(ld), pc))
         self.n_items, self.k, self.n_users = n_items, 0, 0
         self.catalogue_items = n_items
         self.item_model = "dense"
+        self.item_precision = precision
         self.has_exclusions = False
         del km, kc
 
-    def fit_ease(self, indptr, indices, values, n_items, lamb, posB=True, want_B=False):
+    def fit_ease(self, indptr, indices, values, n_items, lamb, posB=True, want_B=False, precision="f32"):
         """EASE closed form on the device (recom_ease.py:75-95) from X = train_set.matrix (CSR); B becomes the
-        dense item matrix of this scorer.  want_B: also return B as a host float64 [I, I] array."""
+        dense item matrix of this scorer.  want_B: also return B as a host float64 [I, I] array.  precision "f64"
+        keeps B in float64 on the device and scores in float64 (the reference's arithmetic)."""
+        if precision not in ("f32", "f64"):
+            raise ValueError("precision must be 'f32' or 'f64'")
+        self.set_option("item_f64", 1 if precision == "f64" else 0)
+        self.item_precision = precision
         pp, kp = self._any_ptr(indptr, np.int64)
         pi, ki = self._any_ptr(indices, np.int32)
         pv, kv = self._any_ptr(values, np.float32)
@@ -434,6 +447,16 @@ class HipScorer:
         self._check(self._lib.ifr_score_dense(self._h, u.data_ptr(), n, out.data_ptr(), out.stride(0), self._stream()))
         if cols > self.n_items:
             self._check(self._lib.ifr_pad_scores_min(self._h, out.data_ptr(), n, out.stride(0), self._stream()))
+        return out
+
+    def score_dense_f64(self, user_ids, out=None):
+        """float64 score rows [n, n_items] of an item matrix installed with precision="f64"."""
+        torch = _torch()
+        u = self._dev_users(user_ids)
+        n = u.numel()
+        if out is None:
+            out = torch.empty((n, self.n_items), dtype=torch.float64, device=self.device)
+        self._check(self._lib.ifr_score_dense_f64(self._h, u.data_ptr(), n, out.data_ptr(), out.stride(0), self._stream()))
         return out
 
     def auc_dense(self, user_ids, scores):

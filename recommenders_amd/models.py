@@ -226,13 +226,17 @@ class HipScoringMixin:
         if item_idx is not None and self._hip_item_must_be_known and self.is_unknown_item(item_idx):
             raise ScoreException("Can't make score prediction for item %d" % item_idx)
         eng = self._hip_engine()
-        dense = eng.score_dense(np.asarray([row], np.int32))[0]
+        dense = self._hip_score_row(eng, row)
         if item_idx is None:
             return self._hip_shape_scores(dense.cpu().numpy().astype(self.score_dtype, copy=False))
         return self.score_dtype(dense[int(item_idx)].item())
 
     def _hip_shape_scores(self, scores):
         return scores
+
+    def _hip_score_row(self, eng, row):
+        """The score row of `row` as the device tensor `score` returns values from."""
+        return eng.score_dense(np.asarray([row], np.int32))[0]
 
     _hip_item_must_be_known = True
 
@@ -252,16 +256,17 @@ class HipScoringMixin:
             item_scores = all_scores[cand]
             ranked = np.sort(cand, kind="stable")
         else:
-            known = eng.score_dense(np.asarray([row], np.int32))[0]                 # device fp32 [num_items]
-            if known.numel() != total_items:
+            exact = self._hip_score_row(eng, row)            # device [num_items]: fp32, or fp64 (precision="f64")
+            if exact.numel() != total_items:
                 # unknown items get the minimum known score (recommender.py:631-635)
-                pad = torch.full((total_items - known.numel(),), known.min().item(), dtype=known.dtype,
-                                 device=known.device)
-                known = torch.cat([known, pad])
+                pad = torch.full((total_items - exact.numel(),), exact.min().item(), dtype=exact.dtype,
+                                 device=exact.device)
+                exact = torch.cat([exact, pad])
+            known = exact.float()                            # ranking keys: the sum rounded once to fp32
             cand = np.arange(self.num_items) if item_indices is None else np.asarray(item_indices)
             cand_dev = torch.as_tensor(cand.astype(np.int32), device=known.device)
             ranked = eng.rank_items(known, cand_dev).cpu().numpy().astype(cand.dtype if cand.dtype.kind == "i" else np.int64)
-            item_scores = known[cand_dev.long()].cpu().numpy().astype(self.score_dtype, copy=False)
+            item_scores = exact[cand_dev.long()].cpu().numpy().astype(self.score_dtype, copy=False)
         if k != -1 and k > len(cand):
             raise ValueError("kth(=%d) out of bounds (%d)" % (k, len(cand)))    # np.argpartition's error
         self.ranked_items[user_idx] = ranked
@@ -416,7 +421,7 @@ class ItemItemScoringMixin(HipScoringMixin):
             eng.set_item_matrix_csr(M.indptr.astype(np.int64), M.indices.astype(np.int32),
                                     M.data.astype(np.float32), M.shape[0], col_scale)
         else:
-            eng.set_item_matrix_dense(M, col_scale)
+            eng.set_item_matrix_dense(M, col_scale, precision=getattr(self, "precision", "f32"))
         self._hip_set_histories(eng, hist, shard=rows is not None)
 
     def _hip_set_histories(self, eng, hist, shard=False):
@@ -429,20 +434,31 @@ class ItemItemScoringMixin(HipScoringMixin):
     def _hip_user_row(self, user_idx):
         return int(user_idx) if self.knows_user(user_idx) else -1
 
+    def _hip_score_row(self, eng, row):
+        if getattr(self, "precision", "f32") == "f64" and eng.item_model == "dense":
+            return eng.score_dense_f64(np.asarray([row], np.int32))[0]
+        return eng.score_dense(np.asarray([row], np.int32))[0]
+
 
 class EASE(ItemItemScoringMixin, RecommenderBase):
     """cornac.models.EASE scoring (cornac/models/ease/recom_ease.py:99-126): s = X[u, :] . B with
     X = train_set.matrix (:75).  init_params: {'B': [I, I]}; without it `fit` builds B with the
     reference's closed form (:78-95) -- build="device": Gram scatter + rocSOLVER Cholesky on the GPU
     (ifr_fit_ease; B goes straight into the scoring engine, `self.B` is its float64 host copy up to
-    `device_B_copy_max_items` items and None above), build="host": the reference's NumPy expressions."""
+    `device_B_copy_max_items` items and None above), build="host": the reference's NumPy expressions.
+    precision="f64" keeps B in float64 on the device and sums every score in float64 in history order, the
+    reference's arithmetic (`score` then agrees with it to a few ulp of float64; rankings use that sum rounded
+    once to fp32); the default "f32" halves the bytes the HBM-bound scoring kernel reads."""
 
     device_B_copy_max_items = 16384          # 2 GiB of float64 on the host
 
     def __init__(self, name="EASEᴿ", lamb=500, posB=True, trainable=True, verbose=True, seed=None, B=None, U=None,
-                 init_params=None, build="device", **kwargs):
+                 init_params=None, build="device", precision="f32", **kwargs):
         RecommenderBase.__init__(self, name=name, trainable=trainable, verbose=verbose)
         self.lamb, self.posB, self.seed = lamb, posB, seed
+        if precision not in ("f32", "f64"):
+            raise ValueError("precision must be 'f32' or 'f64'")
+        self.precision = precision
         self.B = B if B is not None else (init_params or {}).get("B")
         self.U = U
         if build not in ("device", "host"):
@@ -466,7 +482,8 @@ class EASE(ItemItemScoringMixin, RecommenderBase):
                 try:
                     n_items = X.shape[1]
                     self.B = eng.fit_ease(X.indptr.astype(np.int64), X.indices.astype(np.int32), X.data.astype(np.float32),
-                                          n_items, self.lamb, self.posB, want_B=n_items <= self.device_B_copy_max_items)
+                                          n_items, self.lamb, self.posB, want_B=n_items <= self.device_B_copy_max_items,
+                                          precision=self.precision)
                     self._hip_set_histories(eng, X)
                 except Exception:
                     eng.close()

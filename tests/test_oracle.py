@@ -292,6 +292,17 @@ def test_item_dense_restatement_against_reference_ease(toy):
         _close(got.astype(np.float64), ref, 1e-5)
 
 
+def test_item_dense_f64_restatement_against_reference_ease(toy):
+    """The fp64 option: fp64 fma chain in history order vs EASE.score of the reference (float64), 1e-13."""
+    d = toy
+    X = _csr(d, "train")
+    for u, ref in zip(d["ease__score_users"], d["ease__score_vecs"]):
+        hi, hv = _hist(X, int(u))
+        got, got32 = orc.c_score_item_dense_f64(d["ease_B"], hi, hv)
+        _close(got, ref, 1e-13)
+        np.testing.assert_array_equal(got32, got.astype(np.float32))
+
+
 def test_item_restatements_against_reference_rp3(toy):
     """Dense chain and fixed-point CSR accumulation vs RP3_Beta.score of the reference; the two
     forms agree with each other to fp32 rounding, and the fixed-point sum is order-free."""
