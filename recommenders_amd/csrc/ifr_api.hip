@@ -1304,6 +1304,10 @@ int ifr_debug_read_stamps(ifr_handle h, unsigned long long *out, int64_t cap, in
 {
     if (!h || !out || !n) return IFR_ERR_ARG;
     IFR_HIP(h, hipDeviceSynchronize());
+    if (h->mode == MODE_ITEM_CSR && cap >= 16) {          // the CSR top-K kernel's phase counters (make ABLATE=1)
+        *n = ifr::item_sparse_read_phases(out) == 0 ? 16 : 0;
+        return IFR_OK;
+    }
     *n = (int64_t)std::min<size_t>(h->dbg_stamp_count, (size_t)cap);
     if (*n > 0) IFR_HIP(h, hipMemcpy(out, h->ws_met, sizeof(unsigned long long) * (size_t)*n, hipMemcpyDeviceToHost));
     return IFR_OK;

@@ -40,6 +40,7 @@ struct ItemItemParams {
 int launch_item_item(const ItemItemParams &p, bool sparse, bool topk, hipStream_t stream);
 int launch_item_sparse_topk(const ItemItemParams &p, int32_t *out_ids, float *out_scores, hipStream_t stream);
 int item_sparse_pass_capacity();
+int item_sparse_read_phases(unsigned long long *out16);   // dev build only (make ABLATE=1), else -1
 int item_sparse_max_chunks();
 int item_csr_pad();             // entries the CSR index / value arrays must be allocated past nnz
 int item_item_chunk(bool sparse);

@@ -345,6 +345,15 @@ constexpr bool SP_DEV = true;
 #else
 constexpr bool SP_DEV = false;
 #endif
+#ifdef IFR_ABLATE
+// dev: shader-clock cycles of thread 0 per phase, summed over workgroups (tools/time_c5.py prints them)
+static __device__ unsigned long long sp_phase[16];
+#define SP_STAMP(k) do { if (tid == 0 && (blockIdx.x & 63) == 0) { const long long now_ = clock64(); atomicAdd(&sp_phase[k], (unsigned long long)(now_ - sp_last)); sp_last = now_; } } while (0)
+#define SP_COUNT(k) do { if (tid == 0 && (blockIdx.x & 63) == 0) atomicAdd(&sp_phase[k], 1ull); } while (0)
+#else
+#define SP_STAMP(k) do { } while (0)
+#define SP_COUNT(k) do { } while (0)
+#endif
 constexpr int SP_CHUNK = II_SPARSE_PASSES * II_PASS;   // 4096 columns: granularity of cptr
 constexpr int SP_BLOCK = 512;                           // threads per user: three workgroups (6 waves/SIMD, <= 85 VGPRs) per CU
 constexpr int SP_SPT = 7;                               // hash slots per thread
@@ -426,6 +435,9 @@ __global__ __launch_bounds__(SP_BLOCK, 6) void item_sparse_topk_kernel(ItemItemP
     uint32_t *const xbm = tbm + SP_CHUNK / 32;                                                // excluded columns of a chunk
 
     const int tid = threadIdx.x;
+#ifdef IFR_ABLATE
+    long long sp_last = clock64();
+#endif
     const int lane = tid & 63, wave = tid >> 6;
     const int g = tid / II_GROUP, l = tid % II_GROUP;
     const int64_t i = blockIdx.x;
@@ -517,6 +529,7 @@ __global__ __launch_bounds__(SP_BLOCK, 6) void item_sparse_topk_kernel(ItemItemP
         if (single) {
             stage(hb, m1, ca, cb, false);
             __syncthreads();
+            SP_STAMP(2);
             sweep(m1, fn);
         } else {
             for (int64_t base = hb; base < he; base += SP_HIST) {
@@ -553,6 +566,7 @@ __global__ __launch_bounds__(SP_BLOCK, 6) void item_sparse_topk_kernel(ItemItemP
 
     // ---- plan: Tc[c] = entries + exclusions below the start of chunk c
     __syncthreads();
+    SP_STAMP(0);
     for (int64_t base = hb; base < he; base += SP_HIST) {
         const int m = (int)min((int64_t)SP_HIST, he - base);
         if (base != hb) __syncthreads();
@@ -570,6 +584,8 @@ __global__ __launch_bounds__(SP_BLOCK, 6) void item_sparse_topk_kernel(ItemItemP
             Tc[c] += (unsigned long long)ex_lower_bound(c >= (1 << 30) / SP_CHUNK ? 0x7fffffff : c * SP_CHUNK);
     }
     __syncthreads();
+    SP_STAMP(1);
+    SP_COUNT(9);
 
     if (SP_DEV && p.dbg == 101) return;                   // dev ablation 101..105: cumulative early exits, timing only
     // equal shares: ceil(total / cap) passes of about total / passes entries keep the table load even
@@ -609,6 +625,10 @@ __global__ __launch_bounds__(SP_BLOCK, 6) void item_sparse_topk_kernel(ItemItemP
             });
             walk(ca, cb, [&](const int (&c)[4], const float (&w)[4], const bool (&ok)[4], double x) {
                 if (SP_DEV && p.dbg == 102) { if (c[0] + c[1] + c[2] + c[3] + __float_as_int(w[0] + w[1] + w[2] + w[3]) == 0x7ffffff1) vals[0] = 1ull; return; }
+                // An LDS atomic costs about the same with one active lane as with 64 (tools/micro/lds_sparse_lanes), so
+                // the probing is arranged for few wave instructions: two queues of two entries per lane, every round
+                // each lane probes once for the entry at the head of either queue (rounds = the longest queue's
+                // probes, not the sum over the entries of the longest probe sequence among the lanes)
                 // every round probes all four entries (finished ones with key 0: CAS(0 -> 0) changes nothing)
                 uint32_t key[4];
                 int slot[4];
@@ -642,6 +662,8 @@ __global__ __launch_bounds__(SP_BLOCK, 6) void item_sparse_topk_kernel(ItemItemP
                 }
             });
             __syncthreads();
+            SP_STAMP(3);
+            SP_COUNT(8);
             if (SP_DEV && p.dbg == 102) { ca = cb; continue; }
             if (SP_DEV && p.dbg == 103) {
                 for (int v = 0; v < SP_SPT; ++v) { keys[tid + v * SP_BLOCK] = 0u; vals[tid + v * SP_BLOCK] = 0ull; }
@@ -652,9 +674,10 @@ __global__ __launch_bounds__(SP_BLOCK, 6) void item_sparse_topk_kernel(ItemItemP
             uint32_t kk[SP_SPT];
             unsigned long long av[SP_SPT];
 #pragma unroll
-            for (int v = 0; v < SP_SPT; ++v) { kk[v] = keys[tid + v * SP_BLOCK]; av[v] = vals[tid + v * SP_BLOCK]; }
-#pragma unroll
-            for (int v = 0; v < SP_SPT; ++v) { keys[tid + v * SP_BLOCK] = 0u; vals[tid + v * SP_BLOCK] = 0ull; }
+            for (int v = 0; v < SP_SPT; ++v) {                                   // exchange: read and clear in one LDS instruction
+                kk[v] = atomicExch(&keys[tid + v * SP_BLOCK], 0u);
+                av[v] = atomicExch(&vals[tid + v * SP_BLOCK], 0ull);
+            }
 #pragma unroll
             for (int v = 0; v < SP_REG; ++v) {
                 kreg[v] = 0ull;
@@ -720,6 +743,7 @@ __global__ __launch_bounds__(SP_BLOCK, 6) void item_sparse_topk_kernel(ItemItemP
             if (lane == 0) wred[wave] = vk;
         }
         __syncthreads();                                   // every slot is in registers: raw becomes qkey
+        SP_STAMP(4);
         unsigned long long tau;
         if (cnt < K) {
             uint32_t th = 0u;
@@ -735,8 +759,10 @@ __global__ __launch_bounds__(SP_BLOCK, 6) void item_sparse_topk_kernel(ItemItemP
             if (__any(q)) { if (q) qkey[atomicAdd(&s_nq, 1)] = kreg[v]; }
         }
         __syncthreads();
+        SP_STAMP(5);
         rank_merge();
         ca = cb;
+        SP_STAMP(6);
     }
     __syncthreads();
     if (SP_DEV && p.dbg >= 101) return;
@@ -791,6 +817,21 @@ __global__ __launch_bounds__(SP_BLOCK, 6) void item_sparse_topk_kernel(ItemItemP
         out_ids[i * K + tid] = tid < cnt ? (int32_t)(~(uint32_t)k) : -1;
         out_scores[i * K + tid] = tid < cnt ? sp_key_float((uint32_t)(k >> 32)) : -INFINITY;
     }
+    SP_STAMP(7);
+}
+
+// dev (make ABLATE=1): the phase counters, cleared by the read; -1 in a product build
+int item_sparse_read_phases(unsigned long long *out16)
+{
+#ifdef IFR_ABLATE
+    unsigned long long z[16] = {0};
+    if (hipDeviceSynchronize() != hipSuccess || hipMemcpyFromSymbol(out16, HIP_SYMBOL(sp_phase), sizeof(z)) != hipSuccess ||
+        hipMemcpyToSymbol(HIP_SYMBOL(sp_phase), z, sizeof(z)) != hipSuccess) return -3;
+    return 0;
+#else
+    (void)out16;
+    return -1;
+#endif
 }
 
 int launch_item_sparse_topk(const ItemItemParams &p, int32_t *out_ids, float *out_scores, hipStream_t stream)

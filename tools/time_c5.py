@@ -20,3 +20,15 @@ for dbg, cap in [(int(a), c) for a in (sys.argv[2].split(",") if len(sys.argv) >
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t) / 3
     print(f"dbg {dbg} cap {cap}: {dt*1e3:.2f} ms  {nu/dt/1e6:.2f} M users/s", flush=True)
+    import ctypes
+    out = (ctypes.c_ulonglong * 16)()
+    n = ctypes.c_int64(0)
+    sc._lib.ifr_debug_read_stamps(sc._h, out, 16, ctypes.byref(n))
+    if n.value == 16 and out[9]:
+        names = ["prologue", "plan", "bounds+excl+stage", "sweep", "scan+bound", "select", "merge", "zeros+out"]
+        nus, passes = out[9], out[8]
+        tot = sum(out[k] for k in range(8))
+        print("   raw", list(out))
+        print(f"   phases (cycles per user of thread 0; {passes / nus:.2f} passes/user; total {tot / nus:.0f}): " +
+              ", ".join(f"{nm} {out[k] / nus:.0f}" for k, nm in enumerate(names)) +
+              f" | inside sweep (thread 0's wave): loads {out[10] / nus:.0f}, fixed+hash {out[11] / nus:.0f}, atomics {out[12] / nus:.0f}", flush=True)
