@@ -8,7 +8,8 @@
 // RP3-beta item-item form, cornac/models/rp3_beta/graph_recommender.py:24-55, 83-84, 104-115:
 //     P_ui = A / deg(u),  P_iu = A^T / deg(i),  W = P_iu . P_ui   (A = binarised train matrix)
 // instead of the reference's (U+I)^2 cube P^3: transpose by counting sort (hand-written), the sparse
-// product by rocSPARSE SpGEMM in fp64 like SciPy's, rows sorted by one radix sort of (row, column) keys.
+// product pattern by rocSPARSE SpGEMM, rows sorted by one radix sort of (row, column) keys, values by an ordered
+// float64 pass that sums like SciPy's csr_matmat (bit-identical W, run to run and against the host build).
 //
 // G and P are fp64 like the reference's.  The Gram matrix is a scatter of every user's item pairs
 // (nnz_u^2 / 2 fp64 atomics into the stored triangle: HBM-bound, no GEMM to shape: a dense X^T X
@@ -18,6 +19,7 @@
 #include <hip/hip_runtime.h>
 #include <rocblas/rocblas.h>
 #include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_segmented_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
 #include <rocprim/iterator/transform_iterator.hpp>
 #include <rocsolver/rocsolver.h>
@@ -185,6 +187,41 @@ __global__ void rp3_unpack_kernel(const uint64_t *keys, const double *val, int64
     }
 }
 
+// W values in SciPy's summation order.  One wave per item row i: the row's users in ascending order, one after the
+// other; for each, the user's items in parallel (distinct columns) add fl(1/deg(i) * 1/deg(u)) at the column's
+// position in the row's sorted column list.  A fence between two users keeps their additions to a shared column in
+// order, so every W[i, j] is the same left-to-right float64 sum over ascending u that csr_matmat forms
+// (graph_recommender.py:83-84 through scipy.sparse) -- bit for bit, on every run.
+__global__ __launch_bounds__(64) void rp3_numeric_kernel(const int64_t *t_ptr, const int32_t *t_idx, const int64_t *a_ptr,
+                                                         const int32_t *a_idx, const int64_t *c_ptr, const uint64_t *keys,
+                                                         double *val, int64_t n_items)
+{
+    const int lane = threadIdx.x;
+    for (int64_t i = blockIdx.x; i < n_items; i += gridDim.x) {
+        const int64_t cb = c_ptr[i], ce = c_ptr[i + 1];
+        for (int64_t q = cb + lane; q < ce; q += 64) val[q] = 0.0;
+        __threadfence();
+        const int64_t ub = t_ptr[i], ue = t_ptr[i + 1];
+        if (ue == ub) continue;
+        const double ai = 1.0 / (double)(ue - ub);
+        for (int64_t q = ub; q < ue; ++q) {
+            const int u = t_idx[q];
+            const int64_t b = a_ptr[u], e = a_ptr[u + 1];
+            const double term = ai * (1.0 / (double)(e - b));
+            for (int64_t k = b + lane; k < e; k += 64) {
+                const uint32_t j = (uint32_t)a_idx[k];
+                int64_t lo = cb, hi = ce;                 // column j is in the row: i and j share user u
+                while (lo < hi) {
+                    const int64_t mid = (lo + hi) >> 1;
+                    if ((uint32_t)keys[mid] < j) lo = mid + 1; else hi = mid;
+                }
+                if (lo < ce) unsafeAtomicAdd(&val[lo], term);   // performed at L2, in issue order after the fence
+            }
+            __threadfence();
+        }
+    }
+}
+
 struct to_i64 {
     __host__ __device__ int64_t operator()(unsigned long long x) const { return (int64_t)x; }
 };
@@ -196,18 +233,18 @@ int rp3_build(const int64_t *a_ptr, const int32_t *a_idx, int64_t n_users, int64
         if (err && errlen) snprintf(err, errlen, "ifr_fit_rp3beta: %s (%d)", what, code);
         return -1;
     };
-    if (n_users > (int64_t)0xffffffffu / 256 || n_items > (int64_t)0xffffffffu / 256 || nnz >= ((int64_t)1 << 40))
+    if (n_users > (int64_t)0xffffffffu / 256 || n_items > (int64_t)0xffffffffu / 256 || nnz >= ((int64_t)1 << 32))
         return fail("too many users, items or interactions", 0);
     memset(out, 0, sizeof(*out));
     unsigned long long *cnt = nullptr, *cursor = nullptr;
     int64_t *t_ptr = nullptr, *c_ptr = nullptr, *z_ptr = nullptr;
-    int32_t *t_idx = nullptr, *c_idx = nullptr;
+    int32_t *t_idx = nullptr, *t_idx2 = nullptr, *c_idx = nullptr;
     double *p_val = nullptr, *t_val = nullptr, *c_val = nullptr, *c_val2 = nullptr;
     uint64_t *k_in = nullptr, *k_out = nullptr;
     void *tmp = nullptr, *buf = nullptr;
     rocsparse_spmat_descr dA = nullptr, dB = nullptr, dC = nullptr, dD = nullptr;
     auto cleanup = [&](bool keep_out) {
-        (void)hipFree(cnt); (void)hipFree(cursor); (void)hipFree(t_ptr); (void)hipFree(t_idx); (void)hipFree(p_val);
+        (void)hipFree(cnt); (void)hipFree(cursor); (void)hipFree(t_ptr); (void)hipFree(t_idx); (void)hipFree(t_idx2); (void)hipFree(p_val);
         (void)hipFree(t_val); (void)hipFree(c_val); (void)hipFree(c_val2); (void)hipFree(k_in); (void)hipFree(k_out);
         (void)hipFree(tmp); (void)hipFree(buf); (void)hipFree(c_idx); (void)hipFree(z_ptr);
         if (dA) rocsparse_destroy_spmat_descr(dA);
@@ -247,6 +284,17 @@ int rp3_build(const int64_t *a_ptr, const int32_t *a_idx, int64_t n_users, int64
         hipLaunchKernelGGL(rp3_transpose_kernel, dim3((unsigned)((n_users + 255) / 256)), dim3(256), 0, 0, a_ptr, a_idx, n_users,
                            t_ptr, cursor, p_val, out->p_val32, t_idx, t_val);
     FIT_HIP(hipGetLastError());
+    // users ascending inside every transposed row (the cursor above hands out positions in arrival order): the
+    // numeric pass below adds in this order.  The values of a row are all 1 / deg(item): nothing to permute.
+    if (nnz > 0) {
+        FIT_HIP(hipMalloc((void **)&t_idx2, sizeof(int32_t) * nz1));
+        size_t seg_bytes = 0;
+        FIT_HIP(rocprim::segmented_radix_sort_keys(nullptr, seg_bytes, t_idx, t_idx2, (unsigned)nnz, (unsigned)n_items, t_ptr, t_ptr + 1, 0, 32));
+        (void)hipFree(tmp); tmp = nullptr;
+        FIT_HIP(hipMalloc(&tmp, seg_bytes > 0 ? seg_bytes : 16));
+        FIT_HIP(rocprim::segmented_radix_sort_keys(tmp, seg_bytes, t_idx, t_idx2, (unsigned)nnz, (unsigned)n_items, t_ptr, t_ptr + 1, 0, 32));
+        std::swap(t_idx, t_idx2);
+    }
 
     rocsparse_handle sp = (rocsparse_handle)*rocsparse_cache;
     if (!sp) {
@@ -294,6 +342,9 @@ int rp3_build(const int64_t *a_ptr, const int32_t *a_idx, int64_t n_users, int64
         (void)hipFree(tmp); tmp = nullptr;
         FIT_HIP(hipMalloc(&tmp, sort_bytes > 0 ? sort_bytes : 16));
         FIT_HIP(rocprim::radix_sort_pairs(tmp, sort_bytes, k_in, k_out, c_val, c_val2, (size_t)w_nnz, 0, 32 + row_bits, 0));
+        // rocSPARSE gave the pattern; its values (summed in hash order) are replaced by the ordered sums
+        hipLaunchKernelGGL(rp3_numeric_kernel, dim3((unsigned)std::min<int64_t>(n_items, 8192)), dim3(64), 0, 0, t_ptr, t_idx, a_ptr, a_idx,
+                           c_ptr, k_out, c_val2, n_items);
         hipLaunchKernelGGL(rp3_unpack_kernel, dim3((unsigned)std::min<int64_t>((w_nnz + 255) / 256, 1 << 20)), dim3(256), 0, 0, k_out, c_val2, w_nnz, out->w_idx,
                            out->w_val);
     }
