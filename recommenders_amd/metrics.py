@@ -19,11 +19,23 @@ class RankingMetric:
         raise NotImplementedError()
 
 
+_SCORER = None
+
+
+def _scorer():
+    """The one engine handle the compute() methods share (a handle owns a HIP context entry and workspaces; every
+    compute() call installs the state it needs, so nothing is carried from one call to the next)."""
+    global _SCORER
+    if _SCORER is None or _SCORER._h is None:
+        from .engine import HipScorer
+        _SCORER = HipScorer(0)
+    return _SCORER
+
+
 def _single_user_list_metrics(gt_pos, pd_rank, k):
     """Six per-cut-off values + (mrr, ap) for one ranked list through ifr_eval_ranked_metrics."""
     import torch
-    from .engine import HipScorer
-    sc = HipScorer(0)
+    sc = _scorer()
     gt = np.unique(np.asarray(gt_pos, dtype=np.int32))
     sc.set_truth_csr(np.asarray([0, len(gt)], np.int64), gt)
     ranked = torch.as_tensor(np.asarray(pd_rank, dtype=np.int32).reshape(1, -1), device=sc.device)
@@ -94,8 +106,7 @@ class MAP(RankingMetric):
 
     def compute(self, item_indices, pd_scores, gt_pos, **kwargs):
         import torch
-        from .engine import HipScorer
-        sc = HipScorer(0)
+        sc = _scorer()
         items = np.asarray(item_indices, dtype=np.int32)
         row = torch.full((int(items.max()) + 1,), float("-inf"), dtype=torch.float32, device=sc.device)
         row[torch.as_tensor(items.astype(np.int64), device=sc.device)] = torch.as_tensor(
@@ -112,8 +123,7 @@ class AUC(RankingMetric):
 
     def compute(self, item_indices, pd_scores, gt_pos, gt_neg=None, **kwargs):
         import torch
-        from .engine import HipScorer
-        sc = HipScorer(0)
+        sc = _scorer()
         items = np.asarray(item_indices, dtype=np.int64)
         n_items = int(items.max()) + 1
         scores = np.zeros(n_items, np.float32)
