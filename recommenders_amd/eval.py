@@ -266,8 +266,13 @@ class _CacheOwner:
         done = caches[0]._explicit
         pos = int(np.searchsorted(self.users, u))
         b_max = max(1, min(self.block_users, self.block_pairs // max(1, self.n_items)))
-        block = [int(v) for v in self.users[pos:pos + 4 * b_max] if int(v) not in done and 0 <= int(v) < eng.n_users
-                 and m._hip_user_row(int(v)) == int(v)][:b_max]
+        block = []
+        for v in self.users[pos:pos + 4 * b_max].tolist():
+            if v in done or not 0 <= v < eng.n_users or m._hip_user_row(v) != v:
+                continue
+            block.append(v)
+            if len(block) == b_max:
+                break
         if u not in block:                                 # a user the engine has no row of its own for
             return self._materialise_one(u)
         excl = self.excl_global()
@@ -281,11 +286,20 @@ class _CacheOwner:
         # candidates in ascending item index and the scores aligned with them (recommender.py:643): compaction of
         # the not-excluded columns, row by row
         keep = torch.ones(dense.shape, dtype=torch.bool, device=eng.device)
-        lens = np.asarray([len(self.excl_row(v)) for v in block])
-        if lens.sum():
-            r_idx = torch.as_tensor(np.repeat(np.arange(len(block)), lens), device=eng.device)
-            c_idx = torch.as_tensor(np.concatenate([self.excl_row(v) for v in block]).astype(np.int64), device=eng.device)
-            keep[r_idx, c_idx] = False
+        # the block's exclusion entries straight from the CSR arrays (a SciPy row slice per user costs more than the
+        # user's share of the launches)
+        r = np.asarray(block, np.int64) - self.row0
+        inside = (r >= 0) & (r < self.excl.shape[0])
+        rc = np.where(inside, r, 0)
+        starts = np.where(inside, self.excl.indptr[rc], 0).astype(np.int64)
+        lens = np.where(inside, self.excl.indptr[rc + 1] - self.excl.indptr[rc], 0).astype(np.int64)
+        total = int(lens.sum())
+        if total:
+            r_idx = np.repeat(np.arange(len(block)), lens)
+            first = np.cumsum(lens) - lens                                   # position of every row's first entry
+            src = np.arange(total) - np.repeat(first, lens) + np.repeat(starts, lens)
+            c_idx = self.excl.indices[src].astype(np.int64)
+            keep[torch.as_tensor(r_idx, device=eng.device), torch.as_tensor(c_idx, device=eng.device)] = False
         def to_host(t):
             # page-locked destination: three copies of ~100 KB per user are what this path costs, pageable memory
             # moves them at a fifth of the link rate; the arrays handed out below are views of these buffers
@@ -622,7 +636,8 @@ def ranking_eval(model, metrics, train_set, test_set, val_set=None, rating_thres
     # ---- result caches: lazy, same candidate sets as this evaluation
     if hasattr(model, "rank"):
         old_users = prev.users if (prev is not None and prev.row0 == r0) else np.zeros(0, np.int64)
-        owner = _CacheOwner(model, excl, n_items, np.union1d(old_users, my_users), r0)
+        same = len(old_users) == 0 or (len(old_users) == len(my_users) and np.array_equal(old_users, my_users))
+        owner = _CacheOwner(model, excl, n_items, my_users if same else np.union1d(old_users, my_users), r0)
         model._hip_cache_owner = owner
         for field in ("ranked_items", "item_scores", "item_scores_mapped_indices"):
             cur = getattr(model, field, {})

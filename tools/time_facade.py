@@ -40,4 +40,9 @@ tot = 0
 for u in us:
     tot += len(model.ranked_items[u]) + len(model.item_scores[u]) + len(model.item_scores_mapped_indices[u])
 dt = time.perf_counter() - t
+pr = cProfile.Profile(); pr.enable()
+for u in list(model.ranked_items.keys())[8192:8192 + 4096]:
+    tot += len(model.ranked_items[u])
+pr.disable()
+pstats.Stats(pr).sort_stats("tottime").print_stats(14)
 print(f"lazy caches: {len(us)} users read in {dt:.3f} s = {1e6 * dt / len(us):.1f} us per user ({tot} entries)", flush=True)
