@@ -302,6 +302,11 @@ def run_config(config, args, steps, warmup, world, rank, dev, D, with_cpu, auc=F
                 "frac": achieved / PEAK_HBM_GBS, "traffic": traffic, "traffic_source": traffic_source,
                 "kernel": "item_item_kernel" if dense else "item_sparse_topk_kernel", "avg_launch_ms": avg_ms, "launches": launches,
                 "bytes_per_launch": bytes_per_launch}
+        if not dense:
+            # the HBM roof is the contract's statement for this byte-moving path; what limits the kernel is instruction
+            # issue (constants of the committed counter run, like `traffic`)
+            roof["limiter"] = ("VALU issue: 65 % of the CU's VALU issue slots, LDS pipe 25 % busy, 59 % of wave-cycles "
+                               "waiting (profiles/r02_c5_sq_counters.json)")
         cfg = {"workload": workload, "users_per_gpu": n, "items": w["n_items"], "topk": TOPK,
                "parallelism": f"users sharded x{world}, item matrix replicated"}
     else:

@@ -82,6 +82,24 @@ def test_chunking_does_not_change_results(torch):
         np.testing.assert_array_equal(got[1], ref[1])
 
 
+def test_two_region_grid_does_not_change_results(torch):
+    """More user tiles than resident workgroup slots: the last, partial round (region B of the grid) sweeps shorter
+    item chunks.  Same lists with the split off, and bit-exact against the oracle on both sides of the border."""
+    n_users = 128 * 552 + 17                                     # 553 user tiles on 512 slots; the last one ragged
+    w = _workload(6, n_users, 2048, 32, True, mean=12)
+    sc = _scorer(w)
+    sc.set_option("target_blocks", 1)                            # one item chunk in region A, so that region B's 4 differ
+    users = np.arange(n_users, dtype=np.int32)
+    ids, scores = sc.rank_topk(users, 10)
+    sc.set_option("tail_split", 0)
+    ids1, scores1 = sc.rank_topk(users, 10)
+    assert torch.equal(ids, ids1) and torch.equal(scores, scores1)
+    sample = np.r_[0:300, 128 * 511 - 100:128 * 513 + 100, n_users - 300:n_users].astype(np.int32)
+    o_ids, o_sc, _, _ = _oracle(w, sample, [10], 10, sc.chain_order())
+    np.testing.assert_array_equal(ids.cpu().numpy()[sample], o_ids)
+    np.testing.assert_array_equal(scores.cpu().numpy()[sample], o_sc)
+
+
 def test_user_subset_order_and_ragged_batch(torch):
     w = _workload(6, 500, 2000, 64, False)
     sc = _scorer(w)
