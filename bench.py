@@ -188,7 +188,8 @@ def build_workload(config, args, rank, dev):
         w = synth.make_item(config, n_users=args.users, n_items=args.items,
                             seed=synth.ITEM_CONFIGS[config][3] + 1000 * rank, device=dev)
         if w["M"] is not None:
-            sc.set_item_matrix_dense(w["M"], w["col_scale"])
+            # --item-f64 (variant, not the headline arithmetic): the float64 option of the dense item matrix
+            sc.set_item_matrix_dense(w["M"], w["col_scale"], precision="f64" if args.item_f64 else "f32")
         else:
             sc.set_item_matrix_csr(w["m_ptr"], w["m_idx"], w["m_val"], w["n_items"], w["col_scale"])
         sc.set_history_csr(w["h_ptr"], w["h_idx"], w["h_val"])
@@ -289,8 +290,10 @@ def run_config(config, args, steps, warmup, world, rank, dev, D, with_cpu, auc=F
     sums = sums.cpu().numpy()
     avg_ms = kern_ms / max(launches, 1)
     traffic, traffic_source = measured_traffic(config, n, w["n_items"])
+    if args.item_f64 and config in synth.ITEM_CONFIGS:
+        traffic, traffic_source = None, None                      # the committed counter pass is the fp32 matrix
     if item_model:
-        bytes_per_launch = item_algorithmic_bytes(w)
+        bytes_per_launch = item_algorithmic_bytes(w) * (2.0 if (args.item_f64 and w["M"] is not None) else 1.0)   # fp64 rows: 8 B per entry
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
         dense = w["M"] is not None
         kind = "EASE-style dense item-item B" if dense else "RP3-beta-style sparse item-item W"
@@ -328,7 +331,7 @@ def run_config(config, args, steps, warmup, world, rank, dev, D, with_cpu, auc=F
         "warmup": warmup,
         "ms_per_step": 1e3 * dt / steps,
         "scaling": "weak",
-        "dtype": "f32",
+        "dtype": "f64" if (args.item_f64 and config in synth.ITEM_CONFIGS and w.get("M") is not None) else "f32",
         "data": "synthetic",
         "config": cfg,
         "roofline": roof,
@@ -373,6 +376,7 @@ def main():
     ap.add_argument("--no-extra", action="store_true", help="headline only")
     ap.add_argument("--host-synth", action="store_true", help="c3_mf_shard: NumPy generator (Zipf items) instead of the device one")
     ap.add_argument("--topk", type=int, default=10, help="list length K (default 10, the metric's; 17..128 takes the candidate-buffer variant of the fused kernel)")
+    ap.add_argument("--item-f64", action="store_true", help="c4_ease_mind variant: float64 item matrix and sums (twice the bytes; use --no-cpu)")
     ap.add_argument("--auc", action="store_true", help="second variant of SURVEY.md 8d: also AUC (dense score rows + ifr_auc_dense)")
     args = ap.parse_args()
     global TOPK
