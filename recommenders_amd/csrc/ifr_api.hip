@@ -100,6 +100,8 @@ struct ifr_handle_s {
     int opt_wide_stats = 0;      // count the candidates of the 16 < K <= 128 path (two contended atomics per user: measurement runs only)
     int opt_wide_chunk_cap = 2;  // item chunks of that path beyond the ceil(K / 24) its bound needs (more lists loosen the bound)
     int opt_tail_split = 1;      // two-region grid: the last, partial round of workgroups runs shorter item chunks
+    int opt_pair_topk = 1;       // 16 < K <= 32 of a dot-product model: two 16-lists per user and item chunk + loss check at the
+                                 // merge (0: the candidate-buffer path like K > 32)
     int opt_debug = 0;           // dev-only kernel ablation mode (see TopkParams::dbg)
     int opt_csr_pass = 0;        // dev/test: entries per hash pass of the CSR top-K kernel (0 = the kernel's capacity)
     int64_t opt_catalogue = 0;   // items the dense-row consumers rank (0 = n_items; > n_items: items unknown to the model)
@@ -320,6 +322,7 @@ int ifr_set_option(ifr_handle h, const char *name, int64_t value)
     if (!strcmp(name, "chunks")) h->opt_chunks = (int)value;
     else if (!strcmp(name, "share_bounds")) h->opt_share_bounds = (int)value;
     else if (!strcmp(name, "tail_split")) h->opt_tail_split = (int)value;
+    else if (!strcmp(name, "pair_topk")) h->opt_pair_topk = value != 0;
     else if (!strcmp(name, "item_f64")) h->opt_item_f64 = value != 0;
     else if (!strcmp(name, "wide_stats")) h->opt_wide_stats = (int)value;
     else if (!strcmp(name, "wide_chunk_cap")) h->opt_wide_chunk_cap = (int)std::max<int64_t>(1, value);
@@ -814,7 +817,7 @@ int ifr_rank_topk(ifr_handle h, const int32_t *user_ids, int64_t n, int K, int32
         if (K > IFR_MAX_TOPK_ITEM) return fail(h, IFR_ERR_ARG, "ifr_rank_topk: item-item models: K must be in [1, 32] (larger cut-offs: ifr_score_dense + ifr_select_topk)");
         return rank_topk_item_item(h, user_ids, n, K, K <= 16 ? 16 : 32, out_ids, out_scores, s);
     }
-    if (K > 16) return rank_topk_wide(h, user_ids, n, K, out_ids, out_scores, nullptr, 0, s);
+    if (K > 32 || (K > 16 && !h->opt_pair_topk)) return rank_topk_wide(h, user_ids, n, K, out_ids, out_scores, nullptr, 0, s);
     return rank_topk_factor(h, user_ids, n, K, 16, out_ids, out_scores, nullptr, 0, s);
 }
 
@@ -830,9 +833,12 @@ int ifr_rank_topk_dense(ifr_handle h, const int32_t *user_ids, int64_t n, int K,
     if (ld < (int64_t)h->n_tiles * ifr::TILE_I || (ld & 3) || ((uintptr_t)dense_out & 15))
         return fail(h, IFR_ERR_ARG, "ifr_rank_topk_dense: ld must be a multiple of 4 and >= n_items rounded up to 32, dense_out 16-byte aligned");
     IFR_HIP(h, hipSetDevice(h->device));
-    if (K > 16) return rank_topk_wide(h, user_ids, n, K, out_ids, out_scores, dense_out, ld, (hipStream_t)stream);
+    if (K > 32 || (K > 16 && !h->opt_pair_topk)) return rank_topk_wide(h, user_ids, n, K, out_ids, out_scores, dense_out, ld, (hipStream_t)stream);
     return rank_topk_factor(h, user_ids, n, K, 16, out_ids, out_scores, dense_out, ld, (hipStream_t)stream);
 }
+
+static int redo_from_dense_rows(ifr_handle h, const int32_t *user_ids, const int32_t *overflow_slots, uint32_t n_over, int K,
+                                int32_t *out_ids, float *out_scores, hipStream_t s);
 
 static int rank_topk_factor(ifr_handle h, const int32_t *user_ids, int64_t n, int K, int KL, int32_t *out_ids, float *out_scores,
                             float *dense, int64_t dense_ld, hipStream_t s, void *fixed_ws, size_t fixed_bytes)
@@ -846,8 +852,19 @@ static int rank_topk_factor(ifr_handle h, const int32_t *user_ids, int64_t n, in
         if (lb_bytes + chunk_bytes > fixed_bytes) return fail(h, IFR_ERR_ARG, "ifr_rank_topk_noalloc: batch too large for the static workspace (see IFR_NOALLOC_MAX_USERS)");
         cap_chunks = (int64_t)((fixed_bytes - lb_bytes) / chunk_bytes);
     }
+    // Pair path (16 < K <= 32, KL = 16): a user's two lists per item chunk hold 32 entries, enough for the top K unless
+    // more than 16 of them sit in one list; the merge detects that and those users are ranked again from dense rows.
+    // 2 ... 8 item chunks: at least four lists per user (with two, K = 32 would lose an item for 4 users in 10), at
+    // most 16 (the all-pairs merge reads 16 entries of each into 256 keys).
+    const bool pair = K > KL;
+    if (pair && (K > 2 * KL || fixed_ws)) return fail(h, IFR_ERR_ARG, "ifr_rank_topk: internal: pair path needs K <= 32 and its own workspace");
+    if (pair) cap_chunks = 8;
     int chunk_tiles, n_chunks;
     pick_chunks(h, n, &chunk_tiles, &n_chunks, cap_chunks);
+    if (pair && n_chunks < 2 && h->n_tiles >= 2) {
+        chunk_tiles = (h->n_tiles + 1) / 2;
+        n_chunks = (h->n_tiles + chunk_tiles - 1) / chunk_tiles;
+    }
     const bool store = dense != nullptr;
     const size_t dyn_lds = (h->opt_debug & 64) ? 30000 : 0;     // dev ablation: extra LDS -> one workgroup per CU
     const topk_fn fn = topk_kernel_kd(h->KD, h->has_base, store, false);
@@ -860,7 +877,7 @@ static int rank_topk_factor(ifr_handle h, const int32_t *user_ids, int64_t n, in
         const int64_t W = n_ut * n_chunks, R = W / S, f = W - R * S;
         if (R >= 1 && f > 0 && 4 * f < 3 * S) {
             const int64_t a = R * S / n_chunks, b = n_ut - a;                    // user tiles of regions A and B
-            const int64_t max_c = std::max<int64_t>(1, std::min<int64_t>(64, h->n_tiles / 16));
+            const int64_t max_c = std::max<int64_t>(1, std::min<int64_t>(pair ? 8 : 64, h->n_tiles / 16));
             int64_t cB = std::min(max_c, S / std::max<int64_t>(b, 1));
             if (b > 0 && a > 0 && cB > n_chunks) {
                 n_utA = (int)a;
@@ -881,11 +898,15 @@ static int rank_topk_factor(ifr_handle h, const int32_t *user_ids, int64_t n, in
     const int64_t gridA = (int64_t)n_utA * n_chunks, grid = gridA + (n_ut - n_utA) * n_chunksB;
     if (grid > (int64_t)0x7fffffff / ifr::BLOCK) return fail(h, IFR_ERR_ARG, "ifr_rank_topk: batch too large, split the user list");
     void *ws = fixed_ws;
+    const size_t over_off = (entries * 8 + lb_bytes + 255) & ~(size_t)255;      // pair path: [count, padding][slots n]
     if (!ws) {
-        int rc = grow(h, &h->ws_part, &h->ws_part_bytes, entries * 8 + lb_bytes);
+        int rc = grow(h, &h->ws_part, &h->ws_part_bytes, pair ? over_off + 256 + (size_t)n * 4 : entries * 8 + lb_bytes);
         if (rc) return rc;
         ws = h->ws_part;
     }
+    uint32_t *over_cnt = pair ? (uint32_t *)((char *)ws + over_off) : nullptr;
+    int32_t *over_slots = pair ? (int32_t *)((char *)ws + over_off + 256) : nullptr;
+    if (pair) IFR_HIP(h, hipMemsetAsync(over_cnt, 0, 256, s));
     ifr::TopkParams p;
     p.U = h->U; p.V = h->V; p.ibase = h->ibase; p.ubase = h->ubase;
     p.user_ids = user_ids; p.n_users = h->n_users; p.n = n; p.n_items = (int)h->n_items; p.n_tiles = h->n_tiles;
@@ -931,10 +952,19 @@ static int rank_topk_factor(ifr_handle h, const int32_t *user_ids, int64_t n, in
     // one merge per region: a user of region A holds 2 * n_chunks lists, one of region B 2 * n_chunksB
     const int64_t offB = p.part_offB;
     if (KL != 16) return fail(h, IFR_ERR_ARG, "ifr_rank_topk: internal: lane lists are 16 entries");
-    ifr::launch_merge_topk<16>(p.part_scores, p.part_ids, nA, n_chunks * 2, n_chunks * 2, K, out_ids, out_scores, s);
-    ifr::launch_merge_topk<16>(p.part_scores + offB, p.part_ids + offB, nB, n_chunksB * 2, n_chunksB * 2, K, out_ids + nA * K, out_scores + nA * K, s);
+    if (ifr::launch_merge_topk<16>(p.part_scores, p.part_ids, nA, n_chunks * 2, n_chunks * 2, K, out_ids, out_scores, s, over_cnt, over_slots, 0) ||
+        ifr::launch_merge_topk<16>(p.part_scores + offB, p.part_ids + offB, nB, n_chunksB * 2, n_chunksB * 2, K, out_ids + nA * K,
+                                   out_scores + nA * K, s, over_cnt, over_slots, nA))
+        return fail(h, IFR_ERR_ARG, "ifr_rank_topk: internal: merge plan");
     IFR_HIP(h, hipGetLastError());
-    return IFR_OK;
+    if (!pair) return IFR_OK;
+    // the one synchronisation of the pair path: how many users must be ranked again
+    uint32_t n_over = 0;
+    IFR_HIP(h, hipMemcpyAsync(&n_over, over_cnt, sizeof(n_over), hipMemcpyDeviceToHost, s));
+    IFR_HIP(h, hipStreamSynchronize(s));
+    h->wide_overflows += n_over;
+    if (n_over == 0) return IFR_OK;
+    return redo_from_dense_rows(h, user_ids, over_slots, n_over, K, out_ids, out_scores, s);
 }
 
 int ifr_rank_topk_noalloc(ifr_handle h, const int32_t *user_ids, int64_t n, int K, int32_t *out_ids, float *out_scores, void *stream)
@@ -950,6 +980,35 @@ int ifr_rank_topk_noalloc(ifr_handle h, const int32_t *user_ids, int64_t n, int 
                             h->scratch, (size_t)IFR_NOALLOC_SCRATCH_BYTES);
 }
 
+
+// Users the fused path could not finish (candidate buffer overflow, or a 16-list that may have dropped one of the top K)
+// are ranked from dense score rows: exact in every case.  overflow_slots: device, positions in user_ids / the outputs.
+static int redo_from_dense_rows(ifr_handle h, const int32_t *user_ids, const int32_t *overflow_slots, uint32_t n_over, int K,
+                                int32_t *out_ids, float *out_scores, hipStream_t s)
+{
+    int rc;
+    const int64_t ldr = ((int64_t)h->n_tiles * ifr::TILE_I + 3) / 4 * 4;
+    const int64_t rows = std::max<int64_t>(1, std::min<int64_t>(n_over, ((int64_t)1 << 28) / ldr));
+    const size_t fb_need = (size_t)rows * ldr * 4 + (size_t)rows * (4 + (size_t)K * 8) + 256;
+    rc = grow(h, &h->ws_sort, &h->ws_sort_bytes, fb_need);
+    if (rc) return rc;
+    float *rows_buf = (float *)h->ws_sort;
+    int32_t *fb_users = (int32_t *)((char *)h->ws_sort + (size_t)rows * ldr * 4);
+    int32_t *fb_ids = fb_users + rows;
+    float *fb_scores = (float *)(fb_ids + rows * K);
+    for (int64_t b = 0; b < n_over; b += rows) {
+        const int m = (int)std::min<int64_t>(rows, n_over - b);
+        hipLaunchKernelGGL(ifr::gather_ids_kernel, dim3((m + 255) / 256), dim3(256), 0, s, user_ids, overflow_slots + b, m, fb_users);
+        rc = ifr_score_dense(h, fb_users, m, rows_buf, ldr, s);
+        if (rc) return rc;
+        if (ifr::launch_select_topk(rows_buf, ldr, fb_users, m, (int)h->n_items, h->ex_ptr, h->ex_idx, h->ex_rows, K, fb_ids, fb_scores, s))
+            return fail(h, IFR_ERR_HIP, "ifr_rank_topk: fallback selection failed");
+        hipLaunchKernelGGL(ifr::scatter_rows_kernel, dim3((m * K + 255) / 256), dim3(256), 0, s, overflow_slots + b, m, K, fb_ids, fb_scores,
+                           out_ids, out_scores);
+        IFR_HIP(h, hipGetLastError());
+    }
+    return IFR_OK;
+}
 
 static int rank_topk_wide(ifr_handle h, const int32_t *user_ids, int64_t n, int K, int32_t *out_ids, float *out_scores,
                           float *dense, int64_t dense_ld, hipStream_t s)
@@ -1028,27 +1087,7 @@ static int rank_topk_wide(ifr_handle h, const int32_t *user_ids, int64_t n, int 
     h->wide_overflows += n_over;
     if (h->opt_wide_stats) { h->wide_users += n; h->wide_cand += (double)back[1]; h->wide_kept += (double)back[2]; }
     if (n_over == 0) return IFR_OK;
-    const int64_t ldr = ((int64_t)h->n_tiles * ifr::TILE_I + 3) / 4 * 4;
-    const int64_t rows = std::max<int64_t>(1, std::min<int64_t>(n_over, ((int64_t)1 << 28) / ldr));
-    const size_t fb_need = (size_t)rows * ldr * 4 + (size_t)rows * (4 + (size_t)K * 8) + 256;
-    rc = grow(h, &h->ws_sort, &h->ws_sort_bytes, fb_need);
-    if (rc) return rc;
-    float *rows_buf = (float *)h->ws_sort;
-    int32_t *fb_users = (int32_t *)((char *)h->ws_sort + (size_t)rows * ldr * 4);
-    int32_t *fb_ids = fb_users + rows;
-    float *fb_scores = (float *)(fb_ids + rows * K);
-    for (int64_t b = 0; b < n_over; b += rows) {
-        const int m = (int)std::min<int64_t>(rows, n_over - b);
-        hipLaunchKernelGGL(ifr::gather_ids_kernel, dim3((m + 255) / 256), dim3(256), 0, s, user_ids, overflow_slots + b, m, fb_users);
-        rc = ifr_score_dense(h, fb_users, m, rows_buf, ldr, s);
-        if (rc) return rc;
-        if (ifr::launch_select_topk(rows_buf, ldr, fb_users, m, (int)h->n_items, h->ex_ptr, h->ex_idx, h->ex_rows, K, fb_ids, fb_scores, s))
-            return fail(h, IFR_ERR_HIP, "ifr_rank_topk: fallback selection failed");
-        hipLaunchKernelGGL(ifr::scatter_rows_kernel, dim3((m * K + 255) / 256), dim3(256), 0, s, overflow_slots + b, m, K, fb_ids, fb_scores,
-                           out_ids, out_scores);
-        IFR_HIP(h, hipGetLastError());
-    }
-    return IFR_OK;
+    return redo_from_dense_rows(h, user_ids, overflow_slots, n_over, K, out_ids, out_scores, s);
 }
 
 static int sum_columns(ifr_handle h, const double *per_user, const int32_t *evaluated, int64_t n, int ncol,

@@ -319,11 +319,15 @@ __global__ __launch_bounds__(BLOCK, KD > 128 ? 1 : 2) void score_topk_kernel(Top
         // and min(ceil(K/2)-th best of both halves) -- the two lists hold distinct items, so at least K
         // of the user's items reach it; for two random halves it is close to the K-th best of their
         // union, about twice as selective as either K-th best alone.
+        // K > KL (the pair path, 16 < K <= 32): the list cannot certify the user's K-th best; its last entry is only
+        // this list's own admission threshold.  What it drops is caught at the merge (a full list whose last entry
+        // ranks before the user's K-th: that user is ranked again from a dense row).
         const float own = list_tau<KL>(ls, p.K);
+        const float own_c = p.K <= KL ? own : -INFINITY;
         const float ownh = list_tau<KL>(ls, (p.K + 1) >> 1);
-        float ext = fmaxf(__shfl_xor(own, 32), fminf(ownh, __shfl_xor(ownh, 32)));
+        float ext = fmaxf(__shfl_xor(own_c, 32), fminf(ownh, __shfl_xor(ownh, 32)));
         if (p.lb != nullptr) {
-            const uint32_t old = atomicMax(&p.lb[slot], float_to_key(fmaxf(own, ext)));
+            const uint32_t old = atomicMax(&p.lb[slot], float_to_key(fmaxf(own_c, ext)));
             ext = fmaxf(ext, key_to_float(old));
         }
         tau = fmaxf(fmaxf(own, next_below(ext)), tau);
@@ -435,7 +439,7 @@ __global__ __launch_bounds__(BLOCK, KD > 128 ? 1 : 2) void score_topk_kernel(Top
             uint32_t todo = 0;                  // hits that found the lane's pending slots full
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                if (hb[r] != 0) {
+                if (__builtin_expect(hb[r] != 0, 0)) {   // cold: a register without a hit falls through (no taken branch)
                     asm volatile("" ::: "memory");   // keeps this a block of its own behind a scalar branch
                     // Straight-line append: a lane that does not hit (or has no free slot) writes the dump row
                     // pend[PEND] instead of being masked off -- no exec-mask juggling per score register.
@@ -574,15 +578,19 @@ __global__ __launch_bounds__(64) void merge_topk_kernel(const float *part_scores
 // workgroup.
 constexpr int MERGE_WAVES = 4;
 
+// Kl = entries read per list = min(K, KL).  K > KL (pair path): over_cnt / over_slots (not null) receive the users for
+// whom a FULL list's last entry ranks before the user's K-th entry (or who have fewer than K entries in all): that
+// list may have dropped an item of the top K.  slot_base = index of this launch's first user in the caller's batch.
 template <int KL, int NE>
 __global__ __launch_bounds__(64 * MERGE_WAVES) void merge_pairs_kernel(const float *part_scores, const int32_t *part_ids,
-                                                                       int64_t n, int n_lists, int stride_lists, int K,
-                                                                       int32_t *out_ids, float *out_scores)
+                                                                       int64_t n, int n_lists, int stride_lists, int K, int Kl,
+                                                                       int32_t *out_ids, float *out_scores,
+                                                                       uint32_t *over_cnt, int32_t *over_slots, int64_t slot_base)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int64_t u = (int64_t)blockIdx.x * MERGE_WAVES + w;
-    const int E = n_lists * K;                       // <= 64 * NE (host-checked)
+    const int E = n_lists * Kl;                      // <= 64 * NE (host-checked)
     const int Epad = (E + 7) & ~7;
     unsigned long long *keys = reinterpret_cast<unsigned long long *>(smem) + (size_t)w * Epad;
     const bool live = u < n;
@@ -596,7 +604,7 @@ __global__ __launch_bounds__(64 * MERGE_WAVES) void merge_pairs_kernel(const flo
         const int e = lane + 64 * q;
         k[q] = 0; sc[q] = 0.0f;
         if (e < E) {
-            const int l = e / K, i = e - l * K;
+            const int l = e / Kl, i = e - l * Kl;
             const int id = pi[l * KL + i];
             sc[q] = ps[l * KL + i];
             if (id != NO_TILE) {
@@ -623,6 +631,21 @@ __global__ __launch_bounds__(64 * MERGE_WAVES) void merge_pairs_kernel(const flo
 #pragma unroll
     for (int q = 0; q < NE; ++q)
         if (k[q] != 0 && rank[q] < K) { out_ids[u * K + rank[q]] = (int32_t)~(uint32_t)k[q]; out_scores[u * K + rank[q]] = sc[q]; }
+    if (over_cnt != nullptr) {
+        // the user's K-th key (0: fewer than K entries), then every full list's last entry against it
+        unsigned long long kth = 0;
+#pragma unroll
+        for (int q = 0; q < NE; ++q) kth = (k[q] != 0 && rank[q] == K - 1) ? k[q] : kth;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) { const unsigned long long o = __shfl_xor(kth, off); kth = o > kth ? o : kth; }
+        bool lost = false;
+#pragma unroll
+        for (int q = 0; q < NE; ++q) {
+            const int e = lane + 64 * q;
+            lost |= e < E && (e % Kl) == Kl - 1 && k[q] != 0 && k[q] > kth;
+        }
+        if (__any(lost) && lane == 0) over_slots[atomicAdd(over_cnt, 1u)] = (int32_t)(slot_base + u);
+    }
     // fewer than K candidates: pad the tail
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) n_valid += __shfl_xor(n_valid, off);
@@ -630,23 +653,29 @@ __global__ __launch_bounds__(64 * MERGE_WAVES) void merge_pairs_kernel(const flo
 }
 
 // stride_lists: partial lists between two users' blocks in part_scores / part_ids (>= n_lists, the lists that are read)
+// K > KL (pair path): n_lists * KL <= 256 (host-checked) and over_cnt / over_slots set; returns -1 otherwise
 template <int KL>
-inline void launch_merge_topk(const float *part_scores, const int32_t *part_ids, int64_t n, int n_lists, int stride_lists, int K,
-                              int32_t *out_ids, float *out_scores, hipStream_t s)
+inline int launch_merge_topk(const float *part_scores, const int32_t *part_ids, int64_t n, int n_lists, int stride_lists, int K,
+                             int32_t *out_ids, float *out_scores, hipStream_t s, uint32_t *over_cnt = nullptr,
+                             int32_t *over_slots = nullptr, int64_t slot_base = 0)
 {
-    if (n <= 0) return;
-    const int E = n_lists * K;
+    if (n <= 0) return 0;
+    const int Kl = K < KL ? K : KL;
+    const int E = n_lists * Kl;
+    if (K > KL && (E > 256 || over_cnt == nullptr || over_slots == nullptr)) return -1;
+    if (K <= KL) { over_cnt = nullptr; over_slots = nullptr; }
     const unsigned grid4 = (unsigned)((n + MERGE_WAVES - 1) / MERGE_WAVES);
     const size_t smem4 = (size_t)MERGE_WAVES * ((E + 7) & ~7) * 8;
     if (E <= 64)
-        hipLaunchKernelGGL((merge_pairs_kernel<KL, 1>), dim3(grid4), dim3(64 * MERGE_WAVES), smem4, s, part_scores, part_ids, n, n_lists, stride_lists, K, out_ids, out_scores);
+        hipLaunchKernelGGL((merge_pairs_kernel<KL, 1>), dim3(grid4), dim3(64 * MERGE_WAVES), smem4, s, part_scores, part_ids, n, n_lists, stride_lists, K, Kl, out_ids, out_scores, over_cnt, over_slots, slot_base);
     else if (E <= 128)
-        hipLaunchKernelGGL((merge_pairs_kernel<KL, 2>), dim3(grid4), dim3(64 * MERGE_WAVES), smem4, s, part_scores, part_ids, n, n_lists, stride_lists, K, out_ids, out_scores);
+        hipLaunchKernelGGL((merge_pairs_kernel<KL, 2>), dim3(grid4), dim3(64 * MERGE_WAVES), smem4, s, part_scores, part_ids, n, n_lists, stride_lists, K, Kl, out_ids, out_scores, over_cnt, over_slots, slot_base);
     else if (E <= 256)
-        hipLaunchKernelGGL((merge_pairs_kernel<KL, 4>), dim3(grid4), dim3(64 * MERGE_WAVES), smem4, s, part_scores, part_ids, n, n_lists, stride_lists, K, out_ids, out_scores);
+        hipLaunchKernelGGL((merge_pairs_kernel<KL, 4>), dim3(grid4), dim3(64 * MERGE_WAVES), smem4, s, part_scores, part_ids, n, n_lists, stride_lists, K, Kl, out_ids, out_scores, over_cnt, over_slots, slot_base);
     else
         hipLaunchKernelGGL((merge_topk_kernel<KL>), dim3((unsigned)n), dim3(64), (size_t)n_lists * KL * 8, s, part_scores, part_ids, n,
                            n_lists, stride_lists, K, out_ids, out_scores);
+    return 0;
 }
 
 // ------------------------------------------------------------------------------------

@@ -588,3 +588,33 @@ def test_wide_topk_ties_short_lists_and_overflow_fallback(torch):
     np.testing.assert_array_equal(ids.cpu().numpy(), o_ids)
     np.testing.assert_array_equal(scores.cpu().numpy(), o_sc)
     assert 0 < sc3.wide_overflows() <= 150
+
+
+def test_pair_topk_lost_item_is_caught(torch):
+    """16 < K <= 32 (two 16-lists per user and item chunk): when more than 16 of a user's best items sit in ONE list --
+    here the 24 best are the items whose index is 0..3 mod 8 inside the first tiles, i.e. one half-lane's rows of one
+    chunk -- that list drops some of them; the merge notices and those users are ranked again from dense rows."""
+    n_users, n_items, k = 300, 6000, 32
+    rng = np.random.default_rng(12)
+    U = rng.normal(0, 0.1, (n_users, k)).astype(np.float32)
+    V = rng.normal(0, 0.1, (n_items, k)).astype(np.float32)
+    U[:, 0] = 1.0
+    V[:, 0] = 0.0
+    best = np.array([8 * q + r for q in range(6) for r in range(4)])          # 24 items of one half-lane, tiles 0 and 1
+    V[best, 0] = 50.0 + rng.random(len(best)).astype(np.float32)
+    w = dict(U=U, V=V, ubase=None, ibase=None, excl_ptr=np.zeros(n_users + 1, np.int64), excl_idx=np.zeros(0, np.int32),
+             truth_ptr=np.zeros(n_users + 1, np.int64), truth_idx=np.zeros(0, np.int32), n_users=n_users, n_items=n_items, k=k)
+    sc = _scorer(w, truth=False)
+    users = np.arange(n_users, dtype=np.int32)
+    for K in (20, 32):
+        before = sc.wide_overflows()
+        ids, scores = sc.rank_topk(users, K)
+        o_ids, o_sc, _, _ = _oracle(w, users, [K], K, sc.chain_order())
+        np.testing.assert_array_equal(ids.cpu().numpy(), o_ids)
+        np.testing.assert_array_equal(scores.cpu().numpy(), o_sc)
+        assert sc.wide_overflows() - before == n_users                         # every user went through the fallback
+    # the candidate-buffer path gives the same lists
+    sc.set_option("pair_topk", 0)
+    ids2, scores2 = sc.rank_topk(users, 20)
+    o_ids, o_sc, _, _ = _oracle(w, users, [20], 20, sc.chain_order())
+    np.testing.assert_array_equal(ids2.cpu().numpy(), o_ids)
