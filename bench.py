@@ -182,6 +182,8 @@ def build_workload(config, args, rank, dev):
         sc.set_option("debug_mode", dbg)
     if os.environ.get("IFR_CHUNKS"):
         sc.set_option("chunks", int(os.environ["IFR_CHUNKS"]))
+    if os.environ.get("IFR_PAIR_MAX"):
+        sc.set_option("pair_max", int(os.environ["IFR_PAIR_MAX"]))
     if os.environ.get("IFR_WIDE_CHUNK_CAP"):
         sc.set_option("wide_chunk_cap", int(os.environ["IFR_WIDE_CHUNK_CAP"]))
     if config in synth.ITEM_CONFIGS:

@@ -100,6 +100,8 @@ struct ifr_handle_s {
     int opt_wide_stats = 0;      // count the candidates of the 16 < K <= 128 path (two contended atomics per user: measurement runs only)
     int opt_wide_chunk_cap = 2;  // item chunks of that path beyond the ceil(K / 24) its bound needs (more lists loosen the bound)
     int opt_tail_split = 1;      // two-region grid: the last, partial round of workgroups runs shorter item chunks
+    int opt_pair_max = 32;       // largest K of that path.  Up to 128 works and the kernel is faster there (C2, K = 100: 55 % vs 49 %), but with
+                                 // contiguous item chunks a catalogue sorted by score puts the whole top K into one chunk: every user is redone
     int opt_pair_topk = 1;       // 16 < K <= 32 of a dot-product model: two 16-lists per user and item chunk + loss check at the
                                  // merge (0: the candidate-buffer path like K > 32)
     int opt_debug = 0;           // dev-only kernel ablation mode (see TopkParams::dbg)
@@ -323,6 +325,7 @@ int ifr_set_option(ifr_handle h, const char *name, int64_t value)
     else if (!strcmp(name, "share_bounds")) h->opt_share_bounds = (int)value;
     else if (!strcmp(name, "tail_split")) h->opt_tail_split = (int)value;
     else if (!strcmp(name, "pair_topk")) h->opt_pair_topk = value != 0;
+    else if (!strcmp(name, "pair_max")) h->opt_pair_max = (int)std::max<int64_t>(16, std::min<int64_t>(value, IFR_MAX_TOPK));
     else if (!strcmp(name, "item_f64")) h->opt_item_f64 = value != 0;
     else if (!strcmp(name, "wide_stats")) h->opt_wide_stats = (int)value;
     else if (!strcmp(name, "wide_chunk_cap")) h->opt_wide_chunk_cap = (int)std::max<int64_t>(1, value);
@@ -817,7 +820,7 @@ int ifr_rank_topk(ifr_handle h, const int32_t *user_ids, int64_t n, int K, int32
         if (K > IFR_MAX_TOPK_ITEM) return fail(h, IFR_ERR_ARG, "ifr_rank_topk: item-item models: K must be in [1, 32] (larger cut-offs: ifr_score_dense + ifr_select_topk)");
         return rank_topk_item_item(h, user_ids, n, K, K <= 16 ? 16 : 32, out_ids, out_scores, s);
     }
-    if (K > 32 || (K > 16 && !h->opt_pair_topk)) return rank_topk_wide(h, user_ids, n, K, out_ids, out_scores, nullptr, 0, s);
+    if (K > h->opt_pair_max || (K > 16 && !h->opt_pair_topk)) return rank_topk_wide(h, user_ids, n, K, out_ids, out_scores, nullptr, 0, s);
     return rank_topk_factor(h, user_ids, n, K, 16, out_ids, out_scores, nullptr, 0, s);
 }
 
@@ -833,7 +836,7 @@ int ifr_rank_topk_dense(ifr_handle h, const int32_t *user_ids, int64_t n, int K,
     if (ld < (int64_t)h->n_tiles * ifr::TILE_I || (ld & 3) || ((uintptr_t)dense_out & 15))
         return fail(h, IFR_ERR_ARG, "ifr_rank_topk_dense: ld must be a multiple of 4 and >= n_items rounded up to 32, dense_out 16-byte aligned");
     IFR_HIP(h, hipSetDevice(h->device));
-    if (K > 32 || (K > 16 && !h->opt_pair_topk)) return rank_topk_wide(h, user_ids, n, K, out_ids, out_scores, dense_out, ld, (hipStream_t)stream);
+    if (K > h->opt_pair_max || (K > 16 && !h->opt_pair_topk)) return rank_topk_wide(h, user_ids, n, K, out_ids, out_scores, dense_out, ld, (hipStream_t)stream);
     return rank_topk_factor(h, user_ids, n, K, 16, out_ids, out_scores, dense_out, ld, (hipStream_t)stream);
 }
 
@@ -857,13 +860,15 @@ static int rank_topk_factor(ifr_handle h, const int32_t *user_ids, int64_t n, in
     // 2 ... 8 item chunks: at least four lists per user (with two, K = 32 would lose an item for 4 users in 10), at
     // most 16 (the all-pairs merge reads 16 entries of each into 256 keys).
     const bool pair = K > KL;
-    if (pair && (K > 2 * KL || fixed_ws)) return fail(h, IFR_ERR_ARG, "ifr_rank_topk: internal: pair path needs K <= 32 and its own workspace");
+    if (pair && (K > IFR_MAX_TOPK || fixed_ws)) return fail(h, IFR_ERR_ARG, "ifr_rank_topk: internal: list path needs K <= 128 and its own workspace");
     if (pair) cap_chunks = 8;
     int chunk_tiles, n_chunks;
     pick_chunks(h, n, &chunk_tiles, &n_chunks, cap_chunks);
-    if (pair && n_chunks < 2 && h->n_tiles >= 2) {
-        chunk_tiles = (h->n_tiles + 1) / 2;
+    const int min_chunks = std::min(8, std::max(2, (K + 11) / 12));
+    if (pair && n_chunks < min_chunks && h->n_tiles >= 2) {
+        chunk_tiles = std::max(1, h->n_tiles / min_chunks);
         n_chunks = (h->n_tiles + chunk_tiles - 1) / chunk_tiles;
+        if (n_chunks > 8) { chunk_tiles = (h->n_tiles + 7) / 8; n_chunks = (h->n_tiles + chunk_tiles - 1) / chunk_tiles; }
     }
     const bool store = dense != nullptr;
     const size_t dyn_lds = (h->opt_debug & 64) ? 30000 : 0;     // dev ablation: extra LDS -> one workgroup per CU

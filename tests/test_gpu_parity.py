@@ -618,3 +618,19 @@ def test_pair_topk_lost_item_is_caught(torch):
     ids2, scores2 = sc.rank_topk(users, 20)
     o_ids, o_sc, _, _ = _oracle(w, users, [20], 20, sc.chain_order())
     np.testing.assert_array_equal(ids2.cpu().numpy(), o_ids)
+
+
+def test_item_bases_survive_fast_waves(torch):
+    """Regression for a race of round 1: with two LDS slots for the item bases a fast wave stored tile t + 1's bases
+    over tile t - 1's while a slower wave of the workgroup still read them (wrong scores for a few users in 1 of 20
+    launches at k = 32, where the MFMA zone is short).  Many launches of that shape, every one bit-exact."""
+    n_users = 128 * 552 + 17
+    w = _workload(6, n_users, 2048, 32, True, mean=12)
+    users = np.arange(n_users, dtype=np.int32)
+    sc = _scorer(w)
+    o_ids, o_sc, _, _ = _oracle(w, users, [10], 10, sc.chain_order())
+    for rep in range(25):
+        for tb in (1, 4096):
+            sc.set_option("target_blocks", tb)
+            ids, scores = sc.rank_topk(users, 10)
+            assert np.array_equal(ids.cpu().numpy(), o_ids) and np.array_equal(scores.cpu().numpy(), o_sc), (rep, tb)
