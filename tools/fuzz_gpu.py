@@ -47,6 +47,11 @@ for case in range(cases):
     t = time.perf_counter()
     ids, scores = sc.rank_topk(users, K)
     ids, scores = ids.cpu().numpy(), scores.cpu().numpy()
+    for again in range(6):                                           # the same launch again: races show as run-to-run differences
+        i2, s2 = sc.rank_topk(users, K)
+        if not (np.array_equal(i2.cpu().numpy(), ids) and np.array_equal(s2.cpu().numpy(), scores, equal_nan=True)):
+            print('   RUN-TO-RUN DIFFERENCE in repeat', again, flush=True)
+            bad += 1
     kp = sc.chain_order()
     o_ids, o_sc, _, _ = orc.c_ranking_eval_factor(U, V, ib, ub, users, ptr, idx, tptr, np.zeros(0, np.int32), [K], False, K,
                                                   kperm=kp[kp < k], n_threads=8)
