@@ -87,8 +87,16 @@ __global__ __launch_bounds__(AUC_BLOCK) void auc_kernel(const float *scores, int
     int it0 = 0;
     if ((ld & 3) == 0 && (reinterpret_cast<uintptr_t>(scores) & 15) == 0) {
         const int n4 = n_items & ~3;
-        for (int it = 4 * threadIdx.x; it < n4; it += 4 * AUC_BLOCK) {
-            const float4 s = *reinterpret_cast<const float4 *>(row + it);
+        // the row is read two iterations ahead: the searches below are chains of dependent LDS reads, and a load issued
+        // at the top of its own iteration would add a trip to memory to every one of them
+        constexpr int STRIDE = 4 * AUC_BLOCK;
+        const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 s_a = 4 * (int)threadIdx.x < n4 ? *reinterpret_cast<const float4 *>(row + 4 * threadIdx.x) : zero4;
+        float4 s_b = 4 * (int)threadIdx.x + STRIDE < n4 ? *reinterpret_cast<const float4 *>(row + 4 * threadIdx.x + STRIDE) : zero4;
+        for (int it = 4 * threadIdx.x; it < n4; it += STRIDE) {
+            const float4 s = s_a;
+            s_a = s_b;
+            if (it + 2 * STRIDE < n4) s_b = *reinterpret_cast<const float4 *>(row + it + 2 * STRIDE);
             int c0 = 0, c1 = 0, c2 = 0, c3 = 0;                 // elements not greater than s (a prefix of ps)
             for (int step = np2 >> 1; step >= 1; step >>= 1) {
                 const float a0 = ps[c0 + step - 1], a1 = ps[c1 + step - 1], a2 = ps[c2 + step - 1], a3 = ps[c3 + step - 1];
