@@ -155,10 +155,11 @@ __global__ __launch_bounds__(BLOCK, KD > 128 ? 1 : 2) void score_topk_kernel(Top
     constexpr int STAGE = (TILE_I * C4) / BLOCK; // float4 loads per thread per tile
     static_assert((TILE_I * C4) % BLOCK == 0, "tile must split evenly");
     __shared__ __attribute__((aligned(16))) float vt[2][TILE_I][ROW];
-    // item bases: THREE slots.  The select of iteration t reads the bases of tile t - 1 all through its MFMA zone while a
-    // faster wave of the workgroup may already be storing tile t + 1 (the one barrier per tile sits after that store):
-    // with two slots that store landed on the slot being read (round 1's latent race: wrong bases, seen with k <= 32).
-    __shared__ __attribute__((aligned(16))) float ibt[3][TILE_I];
+    // item bases of tile t live in ibt[t & 1].  They are stored at the TOP of iteration t (from the register the
+    // prefetch of iteration t - 1 filled), not with the tile's factors at the end of iteration t - 1: the select of an
+    // iteration reads the OTHER slot all through its MFMA zone, and a store at the end of the previous iteration let a
+    // fast wave overwrite what a slower wave of the workgroup still read (round 1's latent race, seen with k <= 32).
+    __shared__ __attribute__((aligned(16))) float ibt[2][TILE_I];
     __shared__ uint2 pend[PEND + 1][BLOCK];      // row PEND: dump row of the straight-line append
 
     const int tid = threadIdx.x;
@@ -351,17 +352,15 @@ __global__ __launch_bounds__(BLOCK, KD > 128 ? 1 : 2) void score_topk_kernel(Top
             st[q] = *reinterpret_cast<const f32x4 *>(src + (off + (uint32_t)(q * BLOCK * 16)));
         if (HAS_BASE && tid < TILE_I) st_b = p.ibase[t * TILE_I + tid];
     };
-    auto stage_store = [&](int buf, int ib_slot) {
+    auto stage_store = [&](int buf) {
 #pragma unroll
         for (int q = 0; q < STAGE; ++q) {
             const int idx = tid + q * BLOCK;
             const int row = idx / C4, c4 = idx - row * C4;
             *reinterpret_cast<f32x4 *>(&vt[buf][row][c4 * 4]) = st[q];
         }
-        if (HAS_BASE && tid < TILE_I) ibt[ib_slot][tid] = st_b;
     };
-    int ib_cur = 0;                             // ibt slot of the tile being multiplied
-    if (t0 < t1) { stage_load(t0); stage_store(0, 0); }
+    if (t0 < t1) { stage_load(t0); stage_store(0); }
     __syncthreads();
 
     // Software pipeline: iteration t issues the MFMAs of tile t and, in the same basic block,
@@ -384,7 +383,8 @@ __global__ __launch_bounds__(BLOCK, KD > 128 ? 1 : 2) void score_topk_kernel(Top
         if (dbg_stamp) T0 = __builtin_amdgcn_s_memtime();
         const bool dbg_no_stage = (p.dbg & 7) >= 3;   // dev ablation: 3 = no staging, no barrier; 4 = no staging
         const int buf = dbg_no_stage ? 0 : parity;
-        const int ib_prev = ib_cur == 0 ? 2 : ib_cur - 1, ib_next = ib_cur == 2 ? 0 : ib_cur + 1;
+        // bases of tile t (st_b: loaded during the last iteration, or by the prologue) -> the slot nobody reads now
+        if (HAS_BASE && tid < TILE_I) ibt[buf][tid] = st_b;
         if (WIDE && live) {
             // the user's bound word, refreshed every tile: the value loaded during the last tile raises tau now, the
             // next load is issued here and has a whole tile to come back (any workgroup of the user may have raised it)
@@ -413,8 +413,8 @@ __global__ __launch_bounds__(BLOCK, KD > 128 ? 1 : 2) void score_topk_kernel(Top
             f32x4 a_nxt = a_cur;
             if (g + 1 < G) a_nxt = *reinterpret_cast<const f32x4 *>(arow + 8 * (g + 1));
             if (HAS_BASE && g < 4) {
-                // item bases of tile t-1: their slot is not written during this iteration (three slots)
-                const f32x4 b4 = *reinterpret_cast<const f32x4 *>(&ibt[ib_prev][8 * g + 4 * h]);
+                // item bases of tile t-1: slot buf ^ 1, not written during this iteration
+                const f32x4 b4 = *reinterpret_cast<const f32x4 *>(&ibt[buf ^ 1][8 * g + 4 * h]);
                 ibC[4 * g + 0] = b4[0]; ibC[4 * g + 1] = b4[1]; ibC[4 * g + 2] = b4[2]; ibC[4 * g + 3] = b4[3];
             }
             if (g == 0 && dbg_stamp) { asm volatile("" ::"v"(a_cur[0])); T1 = __builtin_amdgcn_s_memtime(); }
@@ -501,8 +501,7 @@ __global__ __launch_bounds__(BLOCK, KD > 128 ? 1 : 2) void score_topk_kernel(Top
             const int valid = p.n_items - t * TILE_I;       // 1..32
             if (valid < 32) mC |= ~0u << valid;
         }
-        if (t + ts < t1 && !dbg_no_stage) stage_store(buf ^ 1, ib_next);
-        ib_cur = ib_next;
+        if (t + ts < t1 && !dbg_no_stage) stage_store(buf ^ 1);
         if ((p.dbg & 7) != 3) __syncthreads();
         if (dbg_stamp) {
             const unsigned long long T3 = __builtin_amdgcn_s_memtime();
