@@ -56,6 +56,12 @@ for case in range(cases):
     o_ids, o_sc, _, _ = orc.c_ranking_eval_factor(U, V, ib, ub, users, ptr, idx, tptr, np.zeros(0, np.int32), [K], False, K,
                                                   kperm=kp[kp < k], n_threads=8)
     ok = np.array_equal(ids, o_ids) and np.array_equal(scores, o_sc, equal_nan=True)
+    if case % 3 == 0:                                                # the variant that also writes the score rows
+        ref_rows = sc.score_dense(users)
+        for again in range(3):
+            i3, s3, rows = sc.rank_topk_dense(users, K)
+            ok &= np.array_equal(i3.cpu().numpy(), o_ids) and np.array_equal(s3.cpu().numpy(), o_sc, equal_nan=True)
+            ok &= bool(torch.equal(rows[:, :n_items], ref_rows[:, :n_items]))
     bad += not ok
     print(f"case {case}: users {n_users} items {n_items} k {k} K {K} bias {bias} {kind} excl {dens} overflow {sc.wide_overflows()} "
           f"{'ok' if ok else 'MISMATCH'} {time.perf_counter() - t:.1f}s", flush=True)
