@@ -102,6 +102,9 @@ struct ifr_handle_s {
     int opt_tail_split = 1;      // two-region grid: the last, partial round of workgroups runs shorter item chunks
     int opt_pair_max = 32;       // largest K of that path.  Up to 128 works and the kernel is faster there (C2, K = 100: 55 % vs 49 %), but with
                                  // contiguous item chunks a catalogue sorted by score puts the whole top K into one chunk: every user is redone
+    int pair_limit = IFR_MAX_TOPK;   // adaptive: a call of the pair path that had to redo more than 5 % of its users (a catalogue sorted
+                                 // by score puts a user's whole top K into one list) sends that K and larger ones to the
+                                 // candidate-buffer path from then on; reset with the model
     int opt_pair_topk = 1;       // 16 < K <= 32 of a dot-product model: two 16-lists per user and item chunk + loss check at the
                                  // merge (0: the candidate-buffer path like K > 32)
     int opt_debug = 0;           // dev-only kernel ablation mode (see TopkParams::dbg)
@@ -226,6 +229,7 @@ void clear_factor_model(ifr_handle h)
 {
     dfree(h->U); dfree(h->V); dfree(h->ibase); dfree(h->ubase);
     h->n_users = 0; h->k = 0; h->KD = 0; h->n_tiles = 0; h->has_base = false;
+    h->pair_limit = IFR_MAX_TOPK;
     if (h->mode == MODE_FACTOR) { h->mode = MODE_NONE; h->n_items = 0; }
 }
 
@@ -820,7 +824,7 @@ int ifr_rank_topk(ifr_handle h, const int32_t *user_ids, int64_t n, int K, int32
         if (K > IFR_MAX_TOPK_ITEM) return fail(h, IFR_ERR_ARG, "ifr_rank_topk: item-item models: K must be in [1, 32] (larger cut-offs: ifr_score_dense + ifr_select_topk)");
         return rank_topk_item_item(h, user_ids, n, K, K <= 16 ? 16 : 32, out_ids, out_scores, s);
     }
-    if (K > h->opt_pair_max || (K > 16 && !h->opt_pair_topk)) return rank_topk_wide(h, user_ids, n, K, out_ids, out_scores, nullptr, 0, s);
+    if (K > std::min(h->opt_pair_max, h->pair_limit) || (K > 16 && !h->opt_pair_topk)) return rank_topk_wide(h, user_ids, n, K, out_ids, out_scores, nullptr, 0, s);
     return rank_topk_factor(h, user_ids, n, K, 16, out_ids, out_scores, nullptr, 0, s);
 }
 
@@ -836,7 +840,7 @@ int ifr_rank_topk_dense(ifr_handle h, const int32_t *user_ids, int64_t n, int K,
     if (ld < (int64_t)h->n_tiles * ifr::TILE_I || (ld & 3) || ((uintptr_t)dense_out & 15))
         return fail(h, IFR_ERR_ARG, "ifr_rank_topk_dense: ld must be a multiple of 4 and >= n_items rounded up to 32, dense_out 16-byte aligned");
     IFR_HIP(h, hipSetDevice(h->device));
-    if (K > h->opt_pair_max || (K > 16 && !h->opt_pair_topk)) return rank_topk_wide(h, user_ids, n, K, out_ids, out_scores, dense_out, ld, (hipStream_t)stream);
+    if (K > std::min(h->opt_pair_max, h->pair_limit) || (K > 16 && !h->opt_pair_topk)) return rank_topk_wide(h, user_ids, n, K, out_ids, out_scores, dense_out, ld, (hipStream_t)stream);
     return rank_topk_factor(h, user_ids, n, K, 16, out_ids, out_scores, dense_out, ld, (hipStream_t)stream);
 }
 
@@ -969,6 +973,7 @@ static int rank_topk_factor(ifr_handle h, const int32_t *user_ids, int64_t n, in
     IFR_HIP(h, hipStreamSynchronize(s));
     h->wide_overflows += n_over;
     if (n_over == 0) return IFR_OK;
+    if (n >= 64 && (int64_t)n_over * 20 > n) h->pair_limit = std::min(h->pair_limit, K - 1);     // this shape does not suit the path
     return redo_from_dense_rows(h, user_ids, over_slots, n_over, K, out_ids, out_scores, s);
 }
 

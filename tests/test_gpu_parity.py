@@ -612,7 +612,9 @@ def test_pair_topk_lost_item_is_caught(torch):
         o_ids, o_sc, _, _ = _oracle(w, users, [K], K, sc.chain_order())
         np.testing.assert_array_equal(ids.cpu().numpy(), o_ids)
         np.testing.assert_array_equal(scores.cpu().numpy(), o_sc)
-        assert sc.wide_overflows() - before == n_users                         # every user went through the fallback
+        if K == 20:
+            assert sc.wide_overflows() - before == n_users                     # every user went through the fallback
+        # ... after which the handle sends K >= 20 to the candidate-buffer path (this shape does not suit the lists)
     # the candidate-buffer path gives the same lists
     sc.set_option("pair_topk", 0)
     ids2, scores2 = sc.rank_topk(users, 20)
