@@ -408,6 +408,7 @@ __global__ __launch_bounds__(BLOCK, KD > 128 ? 1 : 2) void score_topk_kernel(Top
         float s[16], ibC[16];
         unsigned long long hb[16];              // per score register: ballot of the lanes whose score passes (SGPR pairs)
         f32x4 a_cur = *reinterpret_cast<const f32x4 *>(arow);
+        __builtin_amdgcn_s_setprio(0);          // back in line for the MFMA zone (raised in zone B of the last iteration)
 #pragma unroll
         for (int g = 0; g < G; ++g) {
             f32x4 a_nxt = a_cur;
@@ -439,6 +440,9 @@ __global__ __launch_bounds__(BLOCK, KD > 128 ? 1 : 2) void score_topk_kernel(Top
         // ---- zone B: only score registers in which some lane hits are visited, behind wave-uniform scalar
         // branches on the ballots of zone A (a hit tile used to scan every 4-register group that held a hit)
         unsigned long long T2b = 0, T2c = 0;
+        // the select's VALU / LDS instructions compete with the partner wave's MFMAs for the SIMD's issue slot: while this
+        // wave is outside its MFMA zone it goes first (every instruction here would otherwise wait out one more MFMA)
+        __builtin_amdgcn_s_setprio(3);
         unsigned long long hany = 0;
 #pragma unroll
         for (int r = 0; r < 16; ++r) hany |= hb[r];
