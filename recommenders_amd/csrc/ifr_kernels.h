@@ -856,6 +856,7 @@ __global__ __launch_bounds__(BLOCK, 2) void score_dense_kernel(DenseParams p)
             if (t + 1 < t1) stage_load(t + 1);
             const float *vrow = &vt[buf][j][4 * h];
             f32x16 acc = {0};
+            __builtin_amdgcn_s_setprio(0);
 #pragma unroll
             for (int g = 0; g < KD / 8; ++g) {
                 const f32x4 b4 = *reinterpret_cast<const f32x4 *>(vrow + 8 * g);
@@ -869,6 +870,7 @@ __global__ __launch_bounds__(BLOCK, 2) void score_dense_kernel(DenseParams p)
             accC = acc;
             ibC = HAS_BASE ? vt[buf][j][KD] : 0.0f;
         }
+        __builtin_amdgcn_s_setprio(3);                   // outside the MFMA zone this wave goes first (see score_topk_kernel)
         if (t > t0) {                                    // tile t - 1
             const int item = (t - 1) * TILE_I + j;
             if (item < p.n_items) {
