@@ -345,11 +345,18 @@ __global__ __launch_bounds__(BLOCK, KD > 128 ? 1 : 2) void score_topk_kernel(Top
     auto stage_load = [&](int t) {
         // uniform tile base (SGPRs) + 32-bit per-thread byte offset: the scalar-base form of
         // global_load, no 64-bit VALU address arithmetic per tile
-        const char *src = reinterpret_cast<const char *>(p.V) + (int64_t)t * (TILE_I * KD * 4);
-        const uint32_t off = (uint32_t)tid * 16u;
+        // buffer loads: the tile's descriptor is built from scalars (base + t * tile bytes: SALU only), the thread's part
+        // is one loop-invariant 32-bit offset, the quarter of the tile an SGPR offset -- no VALU address arithmetic in
+        // the stretch between the barrier and the tile's first MFMA, where a dependent VALU instruction waits out one
+        // MFMA of the partner wave
+        char *src = const_cast<char *>(reinterpret_cast<const char *>(p.V)) + (int64_t)t * (TILE_I * KD * 4);
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(src, 0, TILE_I * KD * 4, 0x00020000);
 #pragma unroll
-        for (int q = 0; q < STAGE; ++q)
-            st[q] = *reinterpret_cast<const f32x4 *>(src + (off + (uint32_t)(q * BLOCK * 16)));
+        for (int q = 0; q < STAGE; ++q) {
+            typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+            const u32x4_t r = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(tid * 16), q * BLOCK * 16, 0);
+            st[q] = __builtin_bit_cast(f32x4, r);
+        }
         if (HAS_BASE && tid < TILE_I) st_b = p.ibase[t * TILE_I + tid];
     };
     auto stage_store = [&](int buf) {
@@ -820,11 +827,14 @@ __global__ __launch_bounds__(BLOCK, 2) void score_dense_kernel(DenseParams p)
     auto stage_load = [&](int t) {
         // uniform tile base (SGPRs) + 32-bit per-thread byte offset: the scalar-base form of
         // global_load, no 64-bit VALU address arithmetic per tile
-        const char *src = reinterpret_cast<const char *>(p.V) + (int64_t)t * (TILE_I * KD * 4);
-        const uint32_t off = (uint32_t)tid * 16u;
+        char *src = const_cast<char *>(reinterpret_cast<const char *>(p.V)) + (int64_t)t * (TILE_I * KD * 4);
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(src, 0, TILE_I * KD * 4, 0x00020000);
 #pragma unroll
-        for (int q = 0; q < STAGE; ++q)
-            st[q] = *reinterpret_cast<const f32x4 *>(src + (off + (uint32_t)(q * BLOCK * 16)));
+        for (int q = 0; q < STAGE; ++q) {        // scalar-addressed buffer loads, as in score_topk_kernel
+            typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+            const u32x4_t r = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(tid * 16), q * BLOCK * 16, 0);
+            st[q] = __builtin_bit_cast(f32x4, r);
+        }
         if (HAS_BASE && tid < TILE_I) st_b = p.ibase[t * TILE_I + tid];
     };
     auto stage_store = [&](int buf) {
