@@ -454,25 +454,36 @@ __global__ __launch_bounds__(BLOCK, KD > 128 ? 1 : 2) void score_topk_kernel(Top
 #pragma unroll
         for (int r = 0; r < 16; ++r) hany |= hb[r];
         if (hany != 0) {
-            uint32_t todo = 0;                  // hits that found the lane's pending slots full
+            // Straight-line append with ONE instruction on the chain from a score register to the next (the count):
+            // outside its MFMA zone a wave's dependent VALU instructions each wait out an MFMA of the partner wave.
+            // Every lane writes its slot min(cnt, PEND): a lane without a hit scribbles on its next free slot, a full
+            // lane on the dump row pend[PEND]; only a hit advances cnt.  Exclusions (and rows past n_items) are dropped
+            // here, on the rare path: the fp32 MFMA shares the VALU, so a per-score kill in zone A is paid on every tile.
+            const int cnt0 = cnt;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 if (__builtin_expect(hb[r] != 0, 0)) {   // cold: a register without a hit falls through (no taken branch)
                     asm volatile("" ::: "memory");   // keeps this a block of its own behind a scalar branch
-                    // Straight-line append: a lane that does not hit (or has no free slot) writes the dump row
-                    // pend[PEND] instead of being masked off -- no exec-mask juggling per score register.
-                    // Exclusions (and rows past n_items) are dropped here, on the rare path: the fp32 MFMA
-                    // shares the VALU, so a per-score kill in zone A is paid on every tile.
                     const bool hit = (s[r] > seltau) & !((mm >> ((r & 3) + 8 * (r >> 2))) & 1u);
-                    const bool ok = hit & (cnt < PEND);
-                    pend[ok ? cnt : PEND][tid] = make_uint2(__float_as_uint(s[r]), (uint32_t)(item0 + (r & 3) + 8 * (r >> 2)));
-                    cnt += ok ? 1 : 0;
-                    todo |= (hit & !ok) ? (1u << r) : 0u;
+                    pend[min(cnt, PEND)][tid] = make_uint2(__float_as_uint(s[r]), (uint32_t)(item0 + (r & 3) + 8 * (r >> 2)));
+                    cnt += hit ? 1 : 0;
                 }
             }
             if (dbg_stamp) T2b = __builtin_amdgcn_s_memtime();
-            if (__any(todo != 0)) {
-                // drain every lane's pending slots into its register list, raise tau, retry the rest
+            if (__any(cnt > PEND)) {
+                // some lane ran out of slots: its hits beyond the PEND-th of this tile went to the dump row.  Find them
+                // again (same walk, counting only), drain every lane's slots into its register list, raise tau, retry
+                uint32_t todo = 0;
+                int c2 = cnt0;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    if (hb[r] != 0) {
+                        const bool hit = (s[r] > seltau) & !((mm >> ((r & 3) + 8 * (r >> 2))) & 1u);
+                        todo |= (hit & (c2 >= PEND)) ? (1u << r) : 0u;
+                        c2 += hit ? 1 : 0;
+                    }
+                }
+                cnt = min(cnt, PEND);
                 flush();
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
