@@ -522,7 +522,17 @@ def test_wide_topk_bit_exact_vs_oracle(torch, k, bias, K, n_items):
     o_ids, o_sc, _, _ = _oracle(w, users, [K], K, sc.chain_order())
     np.testing.assert_array_equal(ids.cpu().numpy(), o_ids)
     np.testing.assert_array_equal(scores.cpu().numpy(), o_sc)
-    assert sc.wide_overflows() == 0
+    if K > 64:
+        assert sc.wide_overflows() == 0
+    sc.set_option("pair_max", 16)                                              # the candidate-buffer path for every K > 16
+    ids1, scores1 = sc.rank_topk(users, K)
+    np.testing.assert_array_equal(ids1.cpu().numpy(), o_ids)
+    np.testing.assert_array_equal(scores1.cpu().numpy(), o_sc)
+    sc.set_option("pair_max", 128)                                             # ... and the list path for every K
+    ids1, scores1 = sc.rank_topk(users, K)
+    np.testing.assert_array_equal(ids1.cpu().numpy(), o_ids)
+    np.testing.assert_array_equal(scores1.cpu().numpy(), o_sc)
+    sc.set_option("pair_max", 64)
     # placement independent: any chunk count gives the same lists
     for chunks in (1, 5):
         sc.set_option("chunks", chunks)
@@ -582,6 +592,7 @@ def test_wide_topk_ties_short_lists_and_overflow_fallback(torch):
     w3 = dict(U=U, V=V, ubase=None, ibase=None, excl_ptr=np.arange(201, dtype=np.int64), excl_idx=np.full(200, n_items - 1, np.int32),
               truth_ptr=np.zeros(201, np.int64), truth_idx=np.zeros(0, np.int32), n_users=200, n_items=n_items, k=32)
     sc3 = _scorer(w3, truth=False)
+    sc3.set_option("pair_max", 32)                # K = 64 through the candidate buffers (the list path would redo all 200)
     u3 = np.arange(200, dtype=np.int32)
     ids, scores = sc3.rank_topk(u3, 64)
     o_ids, o_sc, _, _ = _oracle(w3, u3, [64], 64, sc3.chain_order())
