@@ -51,7 +51,7 @@ const char *ifr_last_error(ifr_handle h);
 /* Launch tuning (no reference counterpart).  "chunks": item chunks per user tile in the fused
  * kernel (0 = heuristic); "target_blocks": workgroups the heuristic aims for; "catalogue_items":
  * see ifr_pad_scores_min; "share_bounds": 0 switches the per-user bound words between item chunks off;
- * "tail_split": 0 = one grid region; "pair_topk": 0 = 16 < K <= 32 takes the candidate-buffer path like K > 32
+ * "tail_split": 0 = one grid region; "pair_topk": 0 = 16 < K <= 64 takes the candidate-buffer path like K > 64
  * ("pair_max": largest K of the pair path, default 64, at most 128);
  * "wide_chunk_cap", "wide_stats": tuning / statistics of that path; "item_f64": see ifr_fit_ease (none of these
  * changes a result);
