@@ -182,6 +182,8 @@ def build_workload(config, args, rank, dev):
         sc.set_option("debug_mode", dbg)
     if os.environ.get("IFR_CHUNKS"):
         sc.set_option("chunks", int(os.environ["IFR_CHUNKS"]))
+    if os.environ.get("IFR_TARGET_BLOCKS"):
+        sc.set_option("target_blocks", int(os.environ["IFR_TARGET_BLOCKS"]))
     if os.environ.get("IFR_PAIR_MAX"):
         sc.set_option("pair_max", int(os.environ["IFR_PAIR_MAX"]))
     if os.environ.get("IFR_WIDE_CHUNK_CAP"):

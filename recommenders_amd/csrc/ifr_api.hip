@@ -209,6 +209,65 @@ int resident_slots(ifr_handle h, topk_fn fn, size_t dyn_lds)
     return per_cu * cus;
 }
 
+// Launch plan of the fused kernel: W = n_ut * c equal workgroups on S resident slots run in ceil(W / S) rounds, and
+// the last round keeps only (W mod S) slots busy for a whole workgroup's time.  Region A = the user tiles that fill
+// whole rounds with c item chunks each; the rest (region B) is cut into more, shorter chunks that fill ONE round
+// together.  c itself is chosen by a cost model in item-tile times: rounds x (tiles per chunk + a fixed cost per
+// workgroup -- its first tiles fill the lists at full insertion cost, measured ~3 tile times: C2 with one chunk per
+// user tile runs 0.9 % faster than with four) instead of a fixed workgroup count.
+struct GridPlan { int chunk_tiles, n_chunks, n_utA, chunk_tilesB, n_chunksB; };
+
+GridPlan plan_grid(ifr_handle h, int64_t n_ut, int64_t S, int min_chunks, int64_t cap_chunks)
+{
+    const int64_t T = h->n_tiles;
+    const int64_t max_c = std::max<int64_t>(1, std::min<int64_t>(cap_chunks > 0 ? cap_chunks : 64, T / 16));
+    auto region = [&](int64_t c, int *tiles, int *chunks) {
+        *tiles = (int)((T + c - 1) / c);
+        *chunks = (int)((T + *tiles - 1) / *tiles);
+    };
+    // the list path wants min_chunks list pairs per user even on a catalogue of a few tiles (one region then)
+    auto at_least = [&](GridPlan g) {
+        if (g.n_chunks >= min_chunks || T < 2) return g;
+        g.chunk_tiles = (int)std::max<int64_t>(1, T / min_chunks);
+        g.n_chunks = (int)((T + g.chunk_tiles - 1) / g.chunk_tiles);
+        if (cap_chunks > 0 && g.n_chunks > cap_chunks) region(cap_chunks, &g.chunk_tiles, &g.n_chunks);
+        g.n_utA = (int)n_ut; g.chunk_tilesB = g.chunk_tiles; g.n_chunksB = g.n_chunks;
+        return g;
+    };
+    GridPlan best{};
+    if (h->opt_chunks > 0 || !h->opt_tail_split) {                 // forced chunk count, or the one-region heuristic
+        int64_t c = h->opt_chunks > 0 ? h->opt_chunks : (h->opt_target_blocks + n_ut - 1) / n_ut;
+        c = std::max<int64_t>(1, std::min(c, std::max<int64_t>(1, std::min<int64_t>(64, T / 16))));
+        if (cap_chunks > 0) c = std::min(c, cap_chunks);
+        c = std::max<int64_t>(c, std::min<int64_t>(min_chunks, std::max<int64_t>(1, std::min<int64_t>(T, 8))));
+        region(c, &best.chunk_tiles, &best.n_chunks);
+        best.n_utA = (int)n_ut; best.chunk_tilesB = best.chunk_tiles; best.n_chunksB = best.n_chunks;
+        return at_least(best);
+    }
+    const double wg_cost = 3.0;
+    const int64_t c_lo = std::min<int64_t>(std::max<int64_t>(1, min_chunks), std::max<int64_t>(1, std::min<int64_t>(T, 8)));
+    const int64_t c_hi = std::max(c_lo, std::min(max_c, (h->opt_target_blocks + n_ut - 1) / n_ut));
+    double best_t = 0;
+    for (int64_t c = c_lo; c <= c_hi; c++) {
+        GridPlan g;
+        region(c, &g.chunk_tiles, &g.n_chunks);
+        g.n_utA = (int)n_ut; g.chunk_tilesB = g.chunk_tiles; g.n_chunksB = g.n_chunks;
+        const int64_t W = n_ut * g.n_chunks, R = W / S, f = W - R * S;
+        double t = (double)((W + S - 1) / S) * (g.chunk_tiles + wg_cost);
+        if (R >= 1 && f > 0 && 4 * f < 3 * S) {
+            const int64_t a = R * S / g.n_chunks, b = n_ut - a;                  // user tiles of regions A and B
+            const int64_t cB = std::min(max_c, S / std::max<int64_t>(b, 1));
+            if (b > 0 && a > 0 && cB > g.n_chunks) {
+                g.n_utA = (int)a;
+                region(cB, &g.chunk_tilesB, &g.n_chunksB);
+                t = (double)R * (g.chunk_tiles + wg_cost) + (g.chunk_tilesB + wg_cost);
+            }
+        }
+        if (c == c_lo || t < best_t) { best = g; best_t = t; }
+    }
+    return at_least(best);
+}
+
 template <int KD>
 void launch_dense(bool has_base, const ifr::DenseParams &p, int grid, hipStream_t s)
 {
@@ -868,35 +927,13 @@ static int rank_topk_factor(ifr_handle h, const int32_t *user_ids, int64_t n, in
     const bool pair = K > KL;
     if (pair && (K > IFR_MAX_TOPK || fixed_ws)) return fail(h, IFR_ERR_ARG, "ifr_rank_topk: internal: list path needs K <= 128 and its own workspace");
     if (pair) cap_chunks = 8;
-    int chunk_tiles, n_chunks;
-    pick_chunks(h, n, &chunk_tiles, &n_chunks, cap_chunks);
-    const int min_chunks = std::min(8, std::max(2, (K + 11) / 12));
-    if (pair && n_chunks < min_chunks && h->n_tiles >= 2) {
-        chunk_tiles = std::max(1, h->n_tiles / min_chunks);
-        n_chunks = (h->n_tiles + chunk_tiles - 1) / chunk_tiles;
-        if (n_chunks > 8) { chunk_tiles = (h->n_tiles + 7) / 8; n_chunks = (h->n_tiles + chunk_tiles - 1) / chunk_tiles; }
-    }
+    const int min_chunks = pair ? std::min(8, std::max(2, (K + 11) / 12)) : 1;
     const bool store = dense != nullptr;
     const size_t dyn_lds = (h->opt_debug & 64) ? 30000 : 0;     // dev ablation: extra LDS -> one workgroup per CU
     const topk_fn fn = topk_kernel_kd(h->KD, h->has_base, store, false);
-    // Tail balancing: with W = n_ut * n_chunks equal workgroups on S resident slots the last of ceil(W / S) rounds
-    // keeps only (W mod S) slots busy for a whole workgroup's time.  Region A = the user tiles that fill whole
-    // rounds; the rest (region B) is cut into more, shorter item chunks that fill ONE round together.
-    int n_utA = (int)n_ut, chunk_tilesB = chunk_tiles, n_chunksB = n_chunks;
-    if (h->opt_tail_split && h->opt_chunks <= 0) {
-        const int64_t S = resident_slots(h, fn, dyn_lds);
-        const int64_t W = n_ut * n_chunks, R = W / S, f = W - R * S;
-        if (R >= 1 && f > 0 && 4 * f < 3 * S) {
-            const int64_t a = R * S / n_chunks, b = n_ut - a;                    // user tiles of regions A and B
-            const int64_t max_c = std::max<int64_t>(1, std::min<int64_t>(pair ? 8 : 64, h->n_tiles / 16));
-            int64_t cB = std::min(max_c, S / std::max<int64_t>(b, 1));
-            if (b > 0 && a > 0 && cB > n_chunks) {
-                n_utA = (int)a;
-                chunk_tilesB = (int)((h->n_tiles + cB - 1) / cB);
-                n_chunksB = (h->n_tiles + chunk_tilesB - 1) / chunk_tilesB;
-            }
-        }
-    }
+    const GridPlan gp = plan_grid(h, n_ut, resident_slots(h, fn, dyn_lds), min_chunks, cap_chunks);
+    const int chunk_tiles = gp.chunk_tiles, n_chunks = gp.n_chunks;
+    int n_utA = gp.n_utA, chunk_tilesB = gp.chunk_tilesB, n_chunksB = gp.n_chunksB;
     // users of region A / B and their partial-list entries (2 lists of KL entries per user and item chunk)
     int64_t nA = std::min<int64_t>(n, (int64_t)n_utA * ifr::USERS_PER_BLOCK), nB = n - nA;
     size_t entries = ((size_t)nA * n_chunks + (size_t)nB * n_chunksB) * 2 * KL;

@@ -102,11 +102,13 @@ __device__ __forceinline__ float next_below(float x)
 // Sorted insertion into a lane-private descending list.  Strict '>' keeps earlier (smaller
 // item index) entries ahead of later equal scores, which is the canonical tie order because a
 // lane sees its items in ascending index order.
-template <int KL>
+// N <= KL: only the first N entries take part (a list that never needs more than N keeps the rest at -inf).
+template <int KL, int N = KL>
 __device__ __forceinline__ void list_insert(float (&ls)[KL], int (&li)[KL], float x, int id)
 {
+    static_assert(N >= 1 && N <= KL, "list_insert: N entries of a KL list");
 #pragma unroll
-    for (int i = KL - 1; i >= 1; --i) {
+    for (int i = N - 1; i >= 1; --i) {
         const bool ci = x > ls[i];
         const bool cim = x > ls[i - 1];
         const int take = cim ? li[i - 1] : id;
@@ -257,17 +259,17 @@ __global__ __launch_bounds__(BLOCK, KD > 128 ? 1 : 2) void score_topk_kernel(Top
     // A lower bound L on the user's K-th best score (from the partner half-lane or from another
     // item chunk's workgroup, via p.lb) prunes with '>=': s > next_below(L).  The lane's own K-th
     // best prunes with '>' (its list only holds earlier, smaller item ids).
-    if (!WIDE && p.lb != nullptr) tau = next_below(key_to_float(p.lb[slot]));
+    // (a region with ONE item chunk per user tile has nobody to share with: the word is neither read nor raised)
+    const bool share_lb = !WIDE && p.lb != nullptr && lists > 2;
+    if (share_lb) tau = next_below(key_to_float(p.lb[slot]));
     if (WIDE && !live) tau = INFINITY;          // idle lanes of the last user tile must not append for user n - 1
     uint32_t bw_seen = 0;
     int age = 0;                                // WIDE: tiles since the last flush                       // WIDE: the user's bound word as loaded one tile ago
     auto flush_wide = [&]() __attribute__((always_inline)) {
-        int maxc = cnt;
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) maxc = max(maxc, __shfl_xor(maxc, off));
         // every pending entry enters the lane's list; those that still reach the bound are the user's candidates
+        // (rounds while some lane still holds an entry: one vote per round instead of a six-step wave maximum)
         int keep = 0;
-        for (int q = 0; q < maxc; ++q) {
+        for (int q = 0; __any(q < cnt); ++q) {
             const uint2 e = pend[q][tid];
             const float x = (q < cnt) ? __uint_as_float(e.x) : -INFINITY;     // -inf never inserts
             list_insert<KL>(ls, li, x, (int)e.y);
@@ -308,15 +310,33 @@ __global__ __launch_bounds__(BLOCK, KD > 128 ? 1 : 2) void score_topk_kernel(Top
             tau = fmaxf(tau, next_below(B));                                         // s > tau  <=>  s >= B
         }
     };
-    auto flush = [&]() __attribute__((always_inline)) {
+    // full: some lane holds PEND entries (the overflow path), so the rounds are PEND; otherwise they run while a vote
+    // finds a lane with an entry left (a wave maximum by six bpermute steps cost ~700 cycles per flush)
+    auto flush = [&](const bool full) __attribute__((always_inline)) {
         if (WIDE) { flush_wide(); return; }
-        int maxc = cnt;
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) maxc = max(maxc, __shfl_xor(maxc, off));
-        for (int q = 0; q < maxc; ++q) {
-            const uint2 e = pend[q][tid];
-            const float x = (q < cnt) ? __uint_as_float(e.x) : -INFINITY;     // -inf never inserts
-            list_insert<KL>(ls, li, x, (int)e.y);
+        // the user's shared bound as the other item chunks left it: loaded now, used after the insertion rounds (any
+        // value the word ever held is a valid bound, so the older one costs nothing and hides the round trip)
+        uint32_t lb_seen = 0;
+        if (share_lb) lb_seen = __hip_atomic_load(p.lb + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // the rounds read one entry ahead (the LDS latency of round q + 1 behind the insertion of round q);
+        // K <= 10 (the metric's cut-off): entries 10 ... KL - 1 can never reach the result, the insertion skips them
+        uint2 e = pend[0][tid];
+        if (KL > 10 && p.K <= 10) {
+#pragma nounroll
+            for (int q = 0; full ? q < PEND : __any(q < cnt); ++q) {
+                const uint2 en = pend[min(q + 1, PEND)][tid];
+                const float x = (q < cnt) ? __uint_as_float(e.x) : -INFINITY;     // -inf never inserts
+                list_insert<KL, (KL > 10 ? 10 : KL)>(ls, li, x, (int)e.y);
+                e = en;
+            }
+        } else {
+#pragma nounroll
+            for (int q = 0; full ? q < PEND : __any(q < cnt); ++q) {
+                const uint2 en = pend[min(q + 1, PEND)][tid];
+                const float x = (q < cnt) ? __uint_as_float(e.x) : -INFINITY;
+                list_insert<KL>(ls, li, x, (int)e.y);
+                e = en;
+            }
         }
         cnt = 0;
         // Lower bounds on the user's K-th best score: this lane's K-th best, the partner half-lane's,
@@ -332,9 +352,10 @@ __global__ __launch_bounds__(BLOCK, KD > 128 ? 1 : 2) void score_topk_kernel(Top
         // the pair bound needs the two lists to hold K entries between them
         const float pairb = ((p.K + 1) >> 1) <= KL ? fminf(ownh, __shfl_xor(ownh, 32)) : -INFINITY;
         float ext = fmaxf(__shfl_xor(own_c, 32), pairb);
-        if (p.lb != nullptr) {
-            const uint32_t old = atomicMax(&p.lb[slot], float_to_key(fmaxf(own_c, ext)));
-            ext = fmaxf(ext, key_to_float(old));
+        if (share_lb) {
+            const uint32_t mine = float_to_key(fmaxf(own_c, ext));
+            if (mine > lb_seen) atomicMax(&p.lb[slot], mine);          // result unused: no round trip to wait for
+            ext = fmaxf(ext, key_to_float(lb_seen));
         }
         tau = fmaxf(fmaxf(own, next_below(ext)), tau);
     };
@@ -459,6 +480,9 @@ __global__ __launch_bounds__(BLOCK, KD > 128 ? 1 : 2) void score_topk_kernel(Top
             // Every lane writes its slot min(cnt, PEND): a lane without a hit scribbles on its next free slot, a full
             // lane on the dump row pend[PEND]; only a hit advances cnt.  Exclusions (and rows past n_items) are dropped
             // here, on the rare path: the fp32 MFMA shares the VALU, so a per-score kill in zone A is paid on every tile.
+            // A register without a hit costs one scalar compare + branch; nothing else is kept per register (the
+            // overflow path below recomputes what it needs).  A tile without any hit takes ONE branch: not-taken
+            // branches are not free either (walking all 16 on every tile cost C3 2.8 points).
             const int cnt0 = cnt;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -472,19 +496,18 @@ __global__ __launch_bounds__(BLOCK, KD > 128 ? 1 : 2) void score_topk_kernel(Top
             if (dbg_stamp) T2b = __builtin_amdgcn_s_memtime();
             if (__any(cnt > PEND)) {
                 // some lane ran out of slots: its hits beyond the PEND-th of this tile went to the dump row.  Find them
-                // again (same walk, counting only), drain every lane's slots into its register list, raise tau, retry
+                // again (same walk, counting only, every register), drain every lane's slots into its register list,
+                // raise tau, retry
                 uint32_t todo = 0;
                 int c2 = cnt0;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    if (hb[r] != 0) {
-                        const bool hit = (s[r] > seltau) & !((mm >> ((r & 3) + 8 * (r >> 2))) & 1u);
-                        todo |= (hit & (c2 >= PEND)) ? (1u << r) : 0u;
-                        c2 += hit ? 1 : 0;
-                    }
+                    const bool hit = (s[r] > seltau) & !((mm >> ((r & 3) + 8 * (r >> 2))) & 1u);
+                    todo |= (hit & (c2 >= PEND)) ? (1u << r) : 0u;
+                    c2 += hit ? 1 : 0;
                 }
                 cnt = min(cnt, PEND);
-                flush();
+                flush(true);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     if ((todo & (1u << r)) && s[r] > tau) {
@@ -501,7 +524,7 @@ __global__ __launch_bounds__(BLOCK, KD > 128 ? 1 : 2) void score_topk_kernel(Top
         // otherwise lag by up to 16 entries per list, as much as K itself, once hits have become rare
         if (WIDE) {
             ++age;
-            if (t == t0 + ts || (age >= WIDE_AGE && __any(cnt > 0))) { flush(); age = 0; }
+            if (t == t0 + ts || (age >= WIDE_AGE && __any(cnt > 0))) { flush(false); age = 0; }
         }
         // exclusion mask of tile t for the next iteration's select
         mC = 0;
@@ -541,7 +564,7 @@ __global__ __launch_bounds__(BLOCK, KD > 128 ? 1 : 2) void score_topk_kernel(Top
     }
 
     // ---- final drain and write the lane's partial list
-    flush();
+    flush(false);
     if (live && !WIDE) {
         const int64_t base = part_off + ((slot - slot0) * lists + chunk * 2 + h) * KL;
 #pragma unroll

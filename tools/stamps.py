@@ -10,7 +10,7 @@ sc.set_factors(w["U"], w["V"], w["ubase"], w["ibase"]); sc.set_exclusion_csr(w["
 users = torch.arange(w["n_users"], dtype=torch.int32, device="cuda")
 sc._lib.ifr_debug_read_stamps.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.POINTER(ctypes.c_int64)]
 for base in [int(x) for x in sys.argv[1:]] or [0, 2, 3, 64, 66, 67]:
-    sc.set_option("chunks", 4); sc.set_option("debug_mode", base | 128)
+    sc.set_option("chunks", int(os.environ.get("IFR_CHUNKS", "4"))); sc.set_option("debug_mode", base | 128)
     sc.rank_topk(users, 10)
     torch.cuda.synchronize(); sc.profile_enable(True); sc.rank_topk(users, 10); torch.cuda.synchronize()
     ms, _, _ = sc.profile_read(); sc.profile_enable(False)
