@@ -119,15 +119,29 @@ __device__ __forceinline__ void list_insert(float (&ls)[KL], int (&li)[KL], floa
     ls[0] = fmaxf(x, ls[0]);
 }
 
+// ls[k] for a wave-uniform k in [LO, HI): a tree of scalar branches down to one register move.  (Written as a min
+// chain with '(i < K)' selects, hipcc keeps one loop-invariant SGPR mask pair per entry, spills them to VGPR lanes
+// and reads them back around every select: ~90 instructions per call; an 'i == K-1' select chain becomes a
+// scratch-indexed load.)  The empty asm keeps each leaf a block of its own.
+template <int LO, int HI, int KL>
+__device__ __forceinline__ float list_pick(const float (&ls)[KL], int k)
+{
+    if constexpr (HI - LO == 1) {
+        float t = ls[LO];
+        asm volatile("" : "+v"(t));
+        return t;
+    } else {
+        constexpr int MID = (LO + HI) / 2;
+        if (k < MID) return list_pick<LO, MID, KL>(ls, k);
+        return list_pick<MID, HI, KL>(ls, k);
+    }
+}
+
 template <int KL>
 __device__ __forceinline__ float list_tau(const float (&ls)[KL], int K)
 {
-    // ls is descending, so the K-th best is the minimum of the first K entries (written as a
-    // min chain: an 'i == K-1' select chain is turned into a scratch-indexed load by hipcc)
-    float t = ls[0];
-#pragma unroll
-    for (int i = 1; i < KL; ++i) t = (i < K) ? fminf(t, ls[i]) : t;
-    return t;
+    // ls is descending, so the K-th best is entry K - 1 (K >= KL: the last entry)
+    return list_pick<0, KL, KL>(ls, min(max(K, 1), KL) - 1);
 }
 
 // ------------------------------------------------------------------------------------
@@ -419,6 +433,10 @@ __global__ __launch_bounds__(BLOCK, KD > 128 ? 1 : 2) void score_topk_kernel(Top
             tau = fmaxf(tau, next_below(key_to_float(bw_seen)));
             bw_seen = __hip_atomic_load(p.bw + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+        // the tile's first operand read goes out before anything else: its LDS latency is the one stretch after the
+        // barrier that nothing of this wave can cover
+        const float *arow = &vt[buf][j][4 * h];
+        f32x4 a_cur = *reinterpret_cast<const f32x4 *>(arow);
         if (t + ts < t1 && !dbg_no_stage) stage_load(t + ts);
 
         // ---- zone A: 32 items x 32 users x KD on the matrix core (tile t), one k-group of four
@@ -429,13 +447,11 @@ __global__ __launch_bounds__(BLOCK, KD > 128 ? 1 : 2) void score_topk_kernel(Top
         constexpr int SEL_G = G < 16 ? G : 16;  // k-groups that carry select work (KD > 128: the first 16)
         // score registers [16g / SEL_G, 16(g + 1) / SEL_G) are selected in k-group g (KD = 96: 1, 1, 2, 1, 1, 2, ...)
         accN = f32x16{0};
-        const float *arow = &vt[buf][j][4 * h];
         const float seltau = (t > t0 && (p.dbg & 7) < 2) ? tau : INFINITY;
         const int item0 = (t - ts) * TILE_I + 4 * h;          // the tile selected now: the previous one of this workgroup
         const uint32_t mm = mC >> (4 * h);
         float s[16], ibC[16];
         unsigned long long hb[16];              // per score register: ballot of the lanes whose score passes (SGPR pairs)
-        f32x4 a_cur = *reinterpret_cast<const f32x4 *>(arow);
         __builtin_amdgcn_s_setprio(0);          // back in line for the MFMA zone (raised in zone B of the last iteration)
 #pragma unroll
         for (int g = 0; g < G; ++g) {
@@ -471,6 +487,8 @@ __global__ __launch_bounds__(BLOCK, KD > 128 ? 1 : 2) void score_topk_kernel(Top
         // the select's VALU / LDS instructions compete with the partner wave's MFMAs for the SIMD's issue slot: while this
         // wave is outside its MFMA zone it goes first (every instruction here would otherwise wait out one more MFMA)
         __builtin_amdgcn_s_setprio(3);
+        // (the union is formed here: OR-ed into one SGPR pair inside the MFMA zone, each OR waits for its v_cmp and holds
+        // up the wave's next MFMA -- measured -1.9 points at C2)
         unsigned long long hany = 0;
 #pragma unroll
         for (int r = 0; r < 16; ++r) hany |= hb[r];
