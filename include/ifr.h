@@ -51,8 +51,8 @@ const char *ifr_last_error(ifr_handle h);
 /* Launch tuning (no reference counterpart).  "chunks": item chunks per user tile in the fused
  * kernel (0 = heuristic); "target_blocks": workgroups the heuristic aims for; "catalogue_items":
  * see ifr_pad_scores_min; "share_bounds": 0 switches the per-user bound words between item chunks off;
- * "tail_split": 0 = one grid region; "pair_topk": 0 = 16 < K <= 64 takes the candidate-buffer path like K > 64
- * ("pair_max": largest K of the pair path, default 64, at most 128);
+ * "tail_split": 0 = one grid region; "pair_topk": 0 = 16 < K <= 100 takes the candidate-buffer path like K > 100
+ * ("pair_max": largest K of the pair path, default 100, at most 128);
  * "wide_chunk_cap", "wide_stats": tuning / statistics of that path; "item_f64": see ifr_fit_ease (none of these
  * changes a result);
  * "debug_mode" / "csr_pass_entries": development ablations (results may change).  Options are per handle and
@@ -155,11 +155,12 @@ int ifr_set_truth_csr(ifr_handle h, const int64_t *indptr, const int32_t *indice
  * ascending on ties.  out_ids/out_scores: dev [n][K]; unfilled slots (fewer than K
  * candidates) hold id -1 / score -inf.  user_ids: dev [n].
  * 1 <= K <= IFR_MAX_TOPK for dot-product models, IFR_MAX_TOPK_ITEM for item-item models.  K <= 16: lane-private
- * sorted lists, merged per user; the call is asynchronous on `stream`.  16 < K <= 64 (dot-product models): the same
+ * sorted lists, merged per user; the call is asynchronous on `stream`.  16 < K <= 100 (dot-product models): the same
  * kernel; a user's two 16-entry lists per item chunk (2 ... 8 chunks, about K / 12) hold the top K unless more than
  * 16 of them fall into one list -- the merge sees that (a full list whose last entry ranks before the user's K-th)
  * and such a user is ranked again from a dense score row; the call synchronises `stream` once to learn whether any
- * user needs it.  64 < K <= 128 (dot-product models): the lists
+ * user needs it.  100 < K <= 128 (dot-product models), or any K > 16 of a model on which that path had to redo more
+ * than 5 % of a batch: the lists
  * only supply a lower bound of the user's K-th best score, every score that reaches it goes to a per-user candidate
  * buffer (16 K entries, at least 512) and the exact top K is selected from it -- the score matrix still never reaches
  * HBM (Recall@50 / @100, re-ranker pools: recommender.py:644-649, rerankers/reranker.py:620-639).  A user whose buffer

@@ -100,10 +100,11 @@ struct ifr_handle_s {
     int opt_wide_stats = 0;      // count the candidates of the 16 < K <= 128 path (two contended atomics per user: measurement runs only)
     int opt_wide_chunk_cap = 2;  // item chunks of that path beyond the ceil(K / 24) its bound needs (more lists loosen the bound)
     int opt_tail_split = 1;      // two-region grid: the last, partial round of workgroups runs shorter item chunks
-    int opt_pair_max = 64;       // largest K of that path (at most 128).  Measured against the candidate buffers: K = 50 -3 % (C2) / -10 %
-                                 // (C3 shape) per pass, K = 100 -7 % / +2 % (the users redone from 4 MB rows cost more than the kernel
-                                 // gains).  With contiguous item chunks a catalogue sorted by score puts a whole top K into one chunk and
-                                 // every user is redone: pair_limit below then turns the path off for that model
+    int opt_pair_max = 100;      // largest K of that path (at most 128).  Measured against the candidate buffers: K = 50 -3 % (C2) / -10 %
+                                 // (C3 shape) per pass, K = 100 -11.5 % / +1.8 % (0.7 % of the users are redone, at C3 shape from 4 MB
+                                 // rows); K = 128 fills half of the 256 list slots and is redone for 9 % of the users.  With contiguous
+                                 // item chunks a catalogue sorted by score puts a whole top K into one chunk and every user is redone:
+                                 // pair_limit below then turns the path off for that model
     int pair_limit = IFR_MAX_TOPK;   // adaptive: a call of the pair path that had to redo more than 5 % of its users (a catalogue sorted
                                  // by score puts a user's whole top K into one list) sends that K and larger ones to the
                                  // candidate-buffer path from then on; reset with the model

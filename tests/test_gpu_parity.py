@@ -522,17 +522,17 @@ def test_wide_topk_bit_exact_vs_oracle(torch, k, bias, K, n_items):
     o_ids, o_sc, _, _ = _oracle(w, users, [K], K, sc.chain_order())
     np.testing.assert_array_equal(ids.cpu().numpy(), o_ids)
     np.testing.assert_array_equal(scores.cpu().numpy(), o_sc)
-    if K > 64:
-        assert sc.wide_overflows() == 0
+    redone = sc.wide_overflows()                                               # the list path may redo a few users (K <= 100)
     sc.set_option("pair_max", 16)                                              # the candidate-buffer path for every K > 16
     ids1, scores1 = sc.rank_topk(users, K)
     np.testing.assert_array_equal(ids1.cpu().numpy(), o_ids)
     np.testing.assert_array_equal(scores1.cpu().numpy(), o_sc)
+    assert sc.wide_overflows() == redone                                       # ... its buffers hold these workloads
     sc.set_option("pair_max", 128)                                             # ... and the list path for every K
     ids1, scores1 = sc.rank_topk(users, K)
     np.testing.assert_array_equal(ids1.cpu().numpy(), o_ids)
     np.testing.assert_array_equal(scores1.cpu().numpy(), o_sc)
-    sc.set_option("pair_max", 64)
+    sc.set_option("pair_max", 100)
     # placement independent: any chunk count gives the same lists
     for chunks in (1, 5):
         sc.set_option("chunks", chunks)
