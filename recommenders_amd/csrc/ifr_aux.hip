@@ -288,6 +288,7 @@ int launch_rank_full(const float *scores, int64_t ld, const int32_t *user_ids, i
 constexpr int SEL_BLOCK = 256;
 constexpr int SEL_MAXK = 1024;
 constexpr int SEL_BINS = 2048;
+constexpr int SEL_UNROLL = 8;
 
 __global__ __launch_bounds__(SEL_BLOCK) void select_topk_kernel(const float *scores, int64_t ld, const int32_t *user_ids,
                                                                 int n_items, const int64_t *ex_ptr, const int32_t *ex_idx,
@@ -296,7 +297,8 @@ __global__ __launch_bounds__(SEL_BLOCK) void select_topk_kernel(const float *sco
     __shared__ uint32_t hist[SEL_BINS];
     __shared__ unsigned long long cand[SEL_MAXK];
     __shared__ uint32_t wsum[SEL_BLOCK / 64];
-    __shared__ uint32_t s_bin, s_below, s_cnt, s_valid_ex;
+    __shared__ uint32_t s_bin, s_below, s_cnt, s_valid_ex, s_eqn;
+    __shared__ int32_t eqbuf[SEL_MAXK];          // items whose key equals the K-th candidate's (collect sweep)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t i = blockIdx.x;
     const int u = user_ids[i];
@@ -309,7 +311,7 @@ __global__ __launch_bounds__(SEL_BLOCK) void select_topk_kernel(const float *sco
         while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (ex_idx[eb + mid] < it) lo = mid + 1; else hi = mid; }
         return lo < n_ex && ex_idx[eb + lo] == it;
     };
-    if (tid == 0) { s_cnt = 0; s_valid_ex = 0; }
+    if (tid == 0) { s_cnt = 0; s_valid_ex = 0; s_eqn = 0; }
     __syncthreads();
     {   // candidates of this row: all items minus the valid entries of the exclusion row
         int c = 0;
@@ -335,9 +337,19 @@ __global__ __launch_bounds__(SEL_BLOCK) void select_topk_kernel(const float *sco
         const uint32_t dmask = (1u << widths[d]) - 1u;
         for (int b = tid; b < SEL_BINS; b += SEL_BLOCK) hist[b] = 0u;
         __syncthreads();
-        for (int it = tid; it < n_items; it += SEL_BLOCK) {
-            const uint32_t k = desc_key(row[it]);
-            if ((k & pmask) == prefix) atomicAdd(&hist[(k >> sh) & dmask], 1u);
+        // SEL_UNROLL loads of a thread are in flight together: with one at a time a 1 M-item row moved at ~1 GB/s per CU
+        for (int base = 0; base < n_items; base += SEL_BLOCK * SEL_UNROLL) {
+            float v[SEL_UNROLL];
+#pragma unroll
+            for (int e = 0; e < SEL_UNROLL; ++e) {
+                const int it = base + e * SEL_BLOCK + tid;
+                v[e] = it < n_items ? row[it] : 0.0f;
+            }
+#pragma unroll
+            for (int e = 0; e < SEL_UNROLL; ++e) {
+                const uint32_t k = desc_key(v[e]);
+                if (base + e * SEL_BLOCK + tid < n_items && (k & pmask) == prefix) atomicAdd(&hist[(k >> sh) & dmask], 1u);
+            }
         }
         for (int64_t q = eb + tid; q < ee; q += SEL_BLOCK) {
             const int it = ex_idx[q];
@@ -374,28 +386,67 @@ __global__ __launch_bounds__(SEL_BLOCK) void select_topk_kernel(const float *sco
         __syncthreads();
     }
     const uint32_t T = prefix;           // key of the Ke-th candidate; `want` of the candidates with this key are taken
-    // ---- collect in item order: better keys anywhere, equal keys by ascending item index
-    uint32_t taken_eq = 0;
-    for (int base = 0; base < n_items; base += SEL_BLOCK) {
-        const int it = base + tid;
-        bool lt = false, eq = false;
-        uint32_t k = 0;
-        if (it < n_items) {
-            k = desc_key(row[it]);
-            if (k <= T && !excluded(it)) { lt = k < T; eq = k == T; }
+    // ---- collect: better keys anywhere (any order: they are sorted below); of the equal keys the `want` smallest item
+    // indices.  One unordered sweep gathers both kinds; almost always exactly `want` items carry the K-th key and all
+    // of them are taken.  Ties across the boundary: the smallest `want` of the gathered indices, or -- more tied items
+    // than the buffer holds, e.g. a constant row -- one ordered sweep over the row.
+    for (int base = 0; base < n_items; base += SEL_BLOCK * SEL_UNROLL) {
+        float v[SEL_UNROLL];
+#pragma unroll
+        for (int e = 0; e < SEL_UNROLL; ++e) {
+            const int it = base + e * SEL_BLOCK + tid;
+            v[e] = it < n_items ? row[it] : 0.0f;
         }
-        // (the index guard only matters for malformed exclusion rows with duplicates, whose double subtraction skews the histograms)
-        if (lt) { const uint32_t sl = atomicAdd(&s_cnt, 1u); if (sl < (uint32_t)SEL_MAXK) cand[sl] = ((unsigned long long)k << 32) | (uint32_t)it; }
-        const unsigned long long bal = __ballot(eq);
-        if (lane == 0) wsum[wave] = (uint32_t)__popcll(bal);
-        __syncthreads();
-        uint32_t before = taken_eq, all = 0;
-        for (int w = 0; w < SEL_BLOCK / 64; ++w) { if (w < wave) before += wsum[w]; all += wsum[w]; }
-        before += (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
-        if (eq && before < want) { const uint32_t sl = atomicAdd(&s_cnt, 1u); if (sl < (uint32_t)SEL_MAXK) cand[sl] = ((unsigned long long)k << 32) | (uint32_t)it; }
-        taken_eq += all;
-        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < SEL_UNROLL; ++e) {
+            const int it = base + e * SEL_BLOCK + tid;
+            const uint32_t k = desc_key(v[e]);
+            // (the index guard of `excluded` only matters for malformed exclusion rows with duplicates, whose double
+            // subtraction skews the histograms)
+            if (it < n_items && k <= T && !excluded(it)) {
+                if (k < T) {
+                    const uint32_t sl = atomicAdd(&s_cnt, 1u);
+                    if (sl < (uint32_t)SEL_MAXK) cand[sl] = ((unsigned long long)k << 32) | (uint32_t)it;
+                } else {
+                    const uint32_t sl = atomicAdd(&s_eqn, 1u);
+                    if (sl < (uint32_t)SEL_MAXK) eqbuf[sl] = it;
+                }
+            }
+        }
     }
+    __syncthreads();
+    const uint32_t n_lt = s_cnt, n_eq = s_eqn;
+    __syncthreads();
+    if (n_eq <= (uint32_t)SEL_MAXK) {
+        // entry q is taken if fewer than `want` gathered indices are smaller (all of them when n_eq == want)
+        for (uint32_t q = tid; q < n_eq; q += SEL_BLOCK) {
+            const int32_t it = eqbuf[q];
+            uint32_t smaller = 0;
+            if (n_eq > want)
+                for (uint32_t r = 0; r < n_eq; ++r) smaller += eqbuf[r] < it ? 1u : 0u;
+            if (smaller < want) {
+                const uint32_t sl = atomicAdd(&s_cnt, 1u);
+                if (sl < (uint32_t)SEL_MAXK) cand[sl] = ((unsigned long long)T << 32) | (uint32_t)it;
+            }
+        }
+    } else {
+        uint32_t taken_eq = 0;
+        for (int base = 0; base < n_items && taken_eq < want; base += SEL_BLOCK) {
+            const int it = base + tid;
+            const bool eq = it < n_items && desc_key(row[it]) == T && !excluded(it);
+            const unsigned long long bal = __ballot(eq);
+            if (lane == 0) wsum[wave] = (uint32_t)__popcll(bal);
+            __syncthreads();
+            uint32_t before = taken_eq, all = 0;
+            for (int w = 0; w < SEL_BLOCK / 64; ++w) { if (w < wave) before += wsum[w]; all += wsum[w]; }
+            before += (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+            if (eq && before < want) { const uint32_t sl = atomicAdd(&s_cnt, 1u); if (sl < (uint32_t)SEL_MAXK) cand[sl] = ((unsigned long long)T << 32) | (uint32_t)it; }
+            taken_eq += all;
+            __syncthreads();
+        }
+    }
+    (void)n_lt;
+    __syncthreads();
     // ---- sort the Ke keys ascending (bitonic, padded with the worst key)
     int np2 = 1;
     while (np2 < Ke) np2 <<= 1;
