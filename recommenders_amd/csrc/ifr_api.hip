@@ -101,7 +101,7 @@ struct ifr_handle_s {
     int opt_wide_chunk_cap = 2;  // item chunks of that path beyond the ceil(K / 24) its bound needs (more lists loosen the bound)
     int opt_tail_split = 1;      // two-region grid: the last, partial round of workgroups runs shorter item chunks
     int opt_pair_max = 100;      // largest K of that path (at most 128).  Measured against the candidate buffers: K = 50 -3 % (C2) / -10 %
-                                 // (C3 shape) per pass, K = 100 -11.5 % / +1.8 % (0.7 % of the users are redone, at C3 shape from 4 MB
+                                 // (C3 shape) per pass, K = 100 -11.5 % / -5.6 % (0.7 % of the users are redone, at C3 shape from 4 MB
                                  // rows); K = 128 fills half of the 256 list slots and is redone for 9 % of the users.  With contiguous
                                  // item chunks a catalogue sorted by score puts a whole top K into one chunk and every user is redone:
                                  // pair_limit below then turns the path off for that model
