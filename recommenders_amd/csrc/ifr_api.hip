@@ -395,7 +395,13 @@ int ifr_set_option(ifr_handle h, const char *name, int64_t value)
     else if (!strcmp(name, "item_f64")) h->opt_item_f64 = value != 0;
     else if (!strcmp(name, "wide_stats")) h->opt_wide_stats = (int)value;
     else if (!strcmp(name, "wide_chunk_cap")) h->opt_wide_chunk_cap = (int)std::max<int64_t>(1, value);
-    else if (!strcmp(name, "debug_mode")) h->opt_debug = (int)value;
+    else if (!strcmp(name, "debug_mode")) {
+#if !defined(IFR_ABLATE) && !defined(IFR_STAMPS)
+        // bits 0-2 (kernel ablations of the fused kernel) and bit 7 (phase stamps) only exist in a dev build
+        if (value & (7 | 128)) return fail(h, IFR_ERR_ARG, "ifr_set_option: debug_mode ablations need a library built with make ABLATE=1 / STAMPS=1");
+#endif
+        h->opt_debug = (int)value;
+    }
     else if (!strcmp(name, "csr_pass_entries")) h->opt_csr_pass = (int)std::max<int64_t>(0, std::min<int64_t>(value, ifr::item_sparse_pass_capacity()));
     else if (!strcmp(name, "catalogue_items")) {
         if (value != 0 && (value < h->n_items || value > (int64_t)1 << 30))

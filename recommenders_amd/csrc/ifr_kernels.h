@@ -423,7 +423,15 @@ __global__ __launch_bounds__(BLOCK, KD > 128 ? 1 : 2) void score_topk_kernel(Top
     auto tile_step = [&](int t, const f32x16 &accC, f32x16 &accN, int parity) __attribute__((always_inline)) {
         unsigned long long T0 = 0, T1 = 0, T2 = 0;
         if (dbg_stamp) T0 = __builtin_amdgcn_s_memtime();
-        const bool dbg_no_stage = (p.dbg & 7) >= 3;   // dev ablation: 3 = no staging, no barrier; 4 = no staging
+        // dev ablations (make ABLATE=1 or STAMPS=1; otherwise compiled out: a run-time mode costs the tile loop four
+        // scalar branches and a boolean carried through a VGPR): 2 = thresholds never met, 3 = no staging, no
+        // barrier; 4 = no staging
+#if defined(IFR_ABLATE) || defined(IFR_STAMPS)
+        const int dbg_mode = p.dbg & 7;
+#else
+        constexpr int dbg_mode = 0;
+#endif
+        const bool dbg_no_stage = dbg_mode >= 3;
         const int buf = dbg_no_stage ? 0 : parity;
         // bases of tile t (st_b: loaded during the last iteration, or by the prologue) -> the slot nobody reads now
         if (HAS_BASE && tid < TILE_I) ibt[buf][tid] = st_b;
@@ -437,7 +445,8 @@ __global__ __launch_bounds__(BLOCK, KD > 128 ? 1 : 2) void score_topk_kernel(Top
         // barrier that nothing of this wave can cover
         const float *arow = &vt[buf][j][4 * h];
         f32x4 a_cur = *reinterpret_cast<const f32x4 *>(arow);
-        if (t + ts < t1 && !dbg_no_stage) stage_load(t + ts);
+        // (likely: hipcc otherwise lays the every-tile staging and barrier out of line, behind taken branches)
+        if (__builtin_expect(t + ts < t1 && !dbg_no_stage, 1)) stage_load(t + ts);
 
         // ---- zone A: 32 items x 32 users x KD on the matrix core (tile t), one k-group of four
         // MFMAs per step, each step followed by the branch-free part of the select for 128/KD score
@@ -447,7 +456,7 @@ __global__ __launch_bounds__(BLOCK, KD > 128 ? 1 : 2) void score_topk_kernel(Top
         constexpr int SEL_G = G < 16 ? G : 16;  // k-groups that carry select work (KD > 128: the first 16)
         // score registers [16g / SEL_G, 16(g + 1) / SEL_G) are selected in k-group g (KD = 96: 1, 1, 2, 1, 1, 2, ...)
         accN = f32x16{0};
-        const float seltau = (t > t0 && (p.dbg & 7) < 2) ? tau : INFINITY;
+        const float seltau = (t > t0 && dbg_mode < 2) ? tau : INFINITY;
         const int item0 = (t - ts) * TILE_I + 4 * h;          // the tile selected now: the previous one of this workgroup
         const uint32_t mm = mC >> (4 * h);
         float s[16], ibC[16];
@@ -564,8 +573,8 @@ __global__ __launch_bounds__(BLOCK, KD > 128 ? 1 : 2) void score_topk_kernel(Top
             const int valid = p.n_items - t * TILE_I;       // 1..32
             if (valid < 32) mC |= ~0u << valid;
         }
-        if (t + ts < t1 && !dbg_no_stage) stage_store(buf ^ 1);
-        if ((p.dbg & 7) != 3) __syncthreads();
+        if (__builtin_expect(t + ts < t1 && !dbg_no_stage, 1)) stage_store(buf ^ 1);
+        if (__builtin_expect(dbg_mode != 3, 1)) __syncthreads();
         if (dbg_stamp) {
             const unsigned long long T3 = __builtin_amdgcn_s_memtime();
             ph0 += T1 - T0; ph1 += T2 - T1; ph2 += T3 - T2; ph3 += 1;
@@ -901,12 +910,14 @@ __global__ __launch_bounds__(BLOCK, 2) void score_dense_kernel(DenseParams p)
     if (t0 < t1) { stage_load(t0); stage_store(0); }
     __syncthreads();
 
-    // row bases of the 16 accumulator rows (null for rows past the batch): one 64-bit add per store
+    // row bases of the 16 accumulator rows: one 64-bit add per store.  Rows past the batch were loaded as user n - 1
+    // (factors and base above), hold that user's values and rewrite them: no per-row test in the tile loop (sixteen
+    // branches per tile before)
     float *orow[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int64_t sl = slot0 + acc_row(r, h);
-        orow[r] = sl < p.n ? p.out + sl * p.ld : nullptr;
+        orow[r] = p.out + (sl < p.n ? sl : p.n - 1) * p.ld;
     }
     // Software pipeline over two alternating accumulators: iteration t issues the 64 MFMAs of tile t, then
     // adds the bases to and stores tile t - 1 while they execute (same scheme as the fused kernel).
@@ -915,7 +926,7 @@ __global__ __launch_bounds__(BLOCK, 2) void score_dense_kernel(DenseParams p)
     auto tile_step = [&](int t, f32x16 &accC, float &ibC, const f32x16 &accP, float ibP) {
         const int buf = (t - t0) & 1;
         if (t < t1) {
-            if (t + 1 < t1) stage_load(t + 1);
+            if (__builtin_expect(t + 1 < t1, 1)) stage_load(t + 1);
             const float *vrow = &vt[buf][j][4 * h];
             f32x16 acc = {0};
             __builtin_amdgcn_s_setprio(0);
@@ -937,12 +948,10 @@ __global__ __launch_bounds__(BLOCK, 2) void score_dense_kernel(DenseParams p)
             const int item = (t - 1) * TILE_I + j;
             if (item < p.n_items) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    if (orow[r] != nullptr) orow[r][item] = HAS_BASE ? ((ibP + ubr[r]) + accP[r]) : accP[r];
-                }
+                for (int r = 0; r < 16; ++r) orow[r][item] = HAS_BASE ? ((ibP + ubr[r]) + accP[r]) : accP[r];
             }
         }
-        if (t + 1 < t1) stage_store(buf ^ 1);
+        if (__builtin_expect(t + 1 < t1, 1)) stage_store(buf ^ 1);
         __syncthreads();
     };
     for (int t = t0; t <= t1; t += 2) {                  // one step past the end drains the last tile
