@@ -55,7 +55,9 @@ const char *ifr_last_error(ifr_handle h);
  * ("pair_max": largest K of the pair path, default 100, at most 128);
  * "wide_chunk_cap", "wide_stats": tuning / statistics of that path; "item_f64": see ifr_fit_ease (none of these
  * changes a result);
- * "debug_mode" / "csr_pass_entries": development ablations (results may change).  Options are per handle and
+ * "debug_mode" / "csr_pass_entries": development ablations (results may change; the fused kernel's modes, bits 0-2
+ * and 7 of "debug_mode", exist only in a library built with `make ABLATE=1` / `STAMPS=1` and are refused with
+ * IFR_ERR_ARG otherwise; bit 6 = one workgroup per CU works everywhere).  Options are per handle and
  * set only through this call: the library reads no environment variable. */
 int ifr_set_option(ifr_handle h, const char *name, int64_t value);
 

@@ -1,4 +1,5 @@
-"""Dev tool: time the fused kernel under option sweeps on the C2 workload (GPU box)."""
+"""Dev tool: time the fused kernel under option sweeps on the C2 workload (GPU box).
+The debug_mode ablations (bits 0-2) need a library built with `make -C recommenders_amd/csrc ABLATE=1`."""
 import sys, os, time, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
