@@ -49,7 +49,8 @@ int ifr_destroy(ifr_handle h);
 const char *ifr_last_error(ifr_handle h);
 
 /* Launch tuning (no reference counterpart).  "chunks": item chunks per user tile in the fused
- * kernel (0 = heuristic); "target_blocks": workgroups the heuristic aims for; "catalogue_items":
+ * kernel (0 = heuristic); "target_blocks": the launch plan considers up to ceil(target_blocks / user tiles)
+ * item chunks per user tile and picks the cheapest by its cost model (rounds x (tiles per chunk + a fixed cost)); "catalogue_items":
  * see ifr_pad_scores_min; "share_bounds": 0 switches the per-user bound words between item chunks off;
  * "tail_split": 0 = one grid region; "pair_topk": 0 = 16 < K <= 100 takes the candidate-buffer path like K > 100
  * ("pair_max": largest K of the pair path, default 100, at most 128);
