@@ -354,6 +354,35 @@ def test_partial_ranking_ties_short_rows_and_nan(torch):
     assert (ids[2] == -1).all() and ids[5, 0] == 300 and (ids[1, :50].cpu().numpy() == np.arange(650, 700)).all()
 
 
+def test_partial_ranking_long_plateaus(torch):
+    """ifr_select_topk when more items tie with the K-th candidate than its tie buffer holds (1 024): the ordered sweep.
+    Constant rows and a plateau of 3 000 equal scores behind a short head; exclusions inside the plateau."""
+    from recommenders_amd import HipScorer
+    n_items, k = 5000, 8
+    U = np.zeros((4, k), np.float32); V = np.zeros((n_items, k), np.float32)
+    U[:, 0] = 1.0
+    V[:, 0] = 1.0
+    V[4000:4020, 0] = 2.0                                            # a head of 20 better items at high indices
+    excl = [np.zeros(0, int), np.arange(0, 2000, 3), np.arange(4000, 4010), np.arange(0, 4990)]
+    ptr = np.cumsum([0] + [len(e) for e in excl]).astype(np.int64)
+    sc = HipScorer(0)
+    sc.set_factors(U, V, None, None)
+    sc.set_exclusion_csr(ptr, np.concatenate(excl).astype(np.int32))
+    users = np.arange(4, dtype=np.int32)
+    dense = sc.score_dense(users)
+    dense[0, :] = 0.5                                                # one fully constant row
+    full, n_cand = sc.rank_full(users, dense)
+    for K in (7, 40, 1024):
+        ids, scores = sc.select_topk(users, dense, K)
+        want = full[:, :K].clone()
+        want[torch.arange(K, device=want.device)[None, :] >= n_cand[:, None]] = -1
+        assert torch.equal(ids, want)
+        ok = ids >= 0
+        assert torch.equal(scores[ok], torch.gather(dense, 1, ids.clamp(min=0).long())[ok])
+        assert torch.isneginf(scores[~ok]).all()
+    sc.close()
+
+
 def test_dense_row_metrics_equal_the_ranked_list_metrics(torch):
     """ifr_eval_dense_metrics (positions of the positives by counting) against ifr_rank_full +
     ifr_eval_ranked_metrics on the same rows: every column, also with plateaus of tied scores, positives that are
