@@ -418,7 +418,11 @@ __global__ __launch_bounds__(BLOCK, KD > 128 ? 1 : 2) void score_topk_kernel(Top
     unsigned long long ph0 = 0, ph1 = 0, ph2 = 0, ph3 = 0, ph4 = 0, ph5 = 0, ph6 = 0;
     // Two accumulators take turns (tile t multiplies into one while the select reads tile t-1 from
     // the other), so no register hand-over sits between the last MFMA of a tile and the next tile.
-    f32x16 accA = {0}, accB = {0};
+    // accA is what the first iteration selects from (no tile yet): -inf passes no threshold, so the select needs no
+    // 'first iteration' case
+    f32x16 accA, accB = {0};
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accA[r] = -INFINITY;
     uint32_t mC = 0;
     auto tile_step = [&](int t, const f32x16 &accC, f32x16 &accN, int parity) __attribute__((always_inline)) {
         unsigned long long T0 = 0, T1 = 0, T2 = 0;
@@ -456,7 +460,7 @@ __global__ __launch_bounds__(BLOCK, KD > 128 ? 1 : 2) void score_topk_kernel(Top
         constexpr int SEL_G = G < 16 ? G : 16;  // k-groups that carry select work (KD > 128: the first 16)
         // score registers [16g / SEL_G, 16(g + 1) / SEL_G) are selected in k-group g (KD = 96: 1, 1, 2, 1, 1, 2, ...)
         accN = f32x16{0};
-        const float seltau = (t > t0 && dbg_mode < 2) ? tau : INFINITY;
+        const float seltau = dbg_mode < 2 ? tau : INFINITY;
         const int item0 = (t - ts) * TILE_I + 4 * h;          // the tile selected now: the previous one of this workgroup
         const uint32_t mm = mC >> (4 * h);
         float s[16], ibC[16];
