@@ -387,6 +387,20 @@ __device__ __forceinline__ int sp_slot(int col)
 {
     return (int)(((((uint32_t)col * 0x9E3779B1u) >> 16) * (uint32_t)SP_SLOTS) >> 16);
 }
+// Probe stride of a column (double hashing): 14 k + 1, k < 128 -- odd and = 1 mod 7, so coprime with SP_SLOTS = 2^9 * 7 and
+// every probe sequence visits every slot.  With a stride of 1 (linear probing) the longest probe sequence among a wave's
+// lanes -- which sets the number of probing rounds -- grows with the clusters; a key-dependent stride breaks them up.
+static_assert(SP_SLOTS == 512 * 7, "sp_step assumes SP_SLOTS = 2^9 * 7");
+__device__ __forceinline__ int sp_step(int col)
+{
+    const uint32_t h = ((uint32_t)col * 0x85EBCA6Bu) >> 25;          // 7 bits
+    return (int)(h * 14u + 1u);
+}
+__device__ __forceinline__ int sp_next(int slot, int step)
+{
+    slot += step;
+    return slot >= SP_SLOTS ? slot - SP_SLOTS : slot;
+}
 // maximum over the 64 lanes (DPP row shifts + row broadcasts), returned to every lane
 __device__ __forceinline__ uint32_t sp_wave_max(uint32_t v)
 {
@@ -617,10 +631,11 @@ __global__ __launch_bounds__(SP_BLOCK, 6) void item_sparse_topk_kernel(ItemItemP
             for_exclusions(colA, colB, [&](int col) {
                 const uint32_t key = (uint32_t)(col + 1);
                 int slot = sp_slot(col);
+                const int step = sp_step(col);
                 for (;;) {
                     const uint32_t old = atomicCAS(&keys[slot], 0u, key | SP_FLAG);
                     if (old == 0u || (old & ~SP_FLAG) == key) break;
-                    slot = slot + 1 == SP_SLOTS ? 0 : slot + 1;
+                    slot = sp_next(slot, step);
                 }
             });
             walk(ca, cb, [&](const int (&c)[4], const float (&w)[4], const bool (&ok)[4], double x) {
@@ -651,8 +666,9 @@ __global__ __launch_bounds__(SP_BLOCK, 6) void item_sparse_topk_kernel(ItemItemP
                 // the entries whose slot belongs to another column walk on, one entry at a time: only their lanes run
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
+                    const int step = sp_step(c[t]);
                     while (key[t] != 0u) {
-                        slot[t] = slot[t] + 1 == SP_SLOTS ? 0 : slot[t] + 1;
+                        slot[t] = sp_next(slot[t], step);
                         const uint32_t o = atomicCAS(&keys[slot[t]], 0u, key[t]);
                         if (o == 0u || (o & ~SP_FLAG) == key[t]) {
                             if (!(o & SP_FLAG)) atomicAdd(&vals[slot[t]], val[t]);
