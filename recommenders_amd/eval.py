@@ -213,7 +213,18 @@ class LazyRankCache(Mapping):
                 yield int(u)
 
     def __len__(self):
-        return len(set(self._explicit) | set(int(u) for u in self._users))
+        # lazy users + explicit entries that are not lazy users (no Python set of every user: 15 ms at 138 K users)
+        n = len(self._users)
+        if not self._explicit:
+            return n
+        if n == 0:
+            return len(self._explicit)
+        try:
+            ek = np.fromiter(self._explicit.keys(), dtype=np.int64, count=len(self._explicit))
+        except (TypeError, ValueError):
+            return len(set(self._explicit) | set(int(u) for u in self._users))
+        pos = np.minimum(np.searchsorted(self._users, ek), n - 1)
+        return n + int((np.asarray(self._users)[pos] != ek).sum())
 
     def __reduce__(self):                         # pickles as the plain dict the reference writes
         return (dict, (dict(self.items()),))
