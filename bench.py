@@ -177,17 +177,10 @@ def build_workload(config, args, rank, dev):
     """(engine with model + CSRs resident, workload dict with the HOST arrays the CPU baseline samples)."""
     from recommenders_amd import HipScorer, synth
     sc = HipScorer(dev.index)
-    dbg = int(os.environ.get("IFR_DEBUG_MODE", "0"))          # dev-only kernel ablations (tools/): set here, not in the library
-    if dbg:
-        sc.set_option("debug_mode", dbg)
-    if os.environ.get("IFR_CHUNKS"):
-        sc.set_option("chunks", int(os.environ["IFR_CHUNKS"]))
-    if os.environ.get("IFR_TARGET_BLOCKS"):
-        sc.set_option("target_blocks", int(os.environ["IFR_TARGET_BLOCKS"]))
-    if os.environ.get("IFR_PAIR_MAX"):
-        sc.set_option("pair_max", int(os.environ["IFR_PAIR_MAX"]))
-    if os.environ.get("IFR_WIDE_CHUNK_CAP"):
-        sc.set_option("wide_chunk_cap", int(os.environ["IFR_WIDE_CHUNK_CAP"]))
+    for opt in (args.dev or "").split(","):                   # --dev name=value,...: development knobs (tools/), never the default run
+        if opt:
+            name, value = opt.split("=")
+            sc.set_option(name, int(value))
     if config in synth.ITEM_CONFIGS:
         w = synth.make_item(config, n_users=args.users, n_items=args.items,
                             seed=synth.ITEM_CONFIGS[config][3] + 1000 * rank, device=dev)
@@ -381,6 +374,8 @@ def main():
     ap.add_argument("--host-synth", action="store_true", help="c3_mf_shard: NumPy generator (Zipf items) instead of the device one")
     ap.add_argument("--topk", type=int, default=10, help="list length K (default 10, the metric's; 17..128 takes the candidate-buffer variant of the fused kernel)")
     ap.add_argument("--item-f64", action="store_true", help="c4_ease_mind variant: float64 item matrix and sums (twice the bytes; use --no-cpu)")
+    ap.add_argument("--dev", default="", help="development only: comma-separated library options name=value (debug_mode, chunks, "
+                    "target_blocks, pair_max, wide_chunk_cap, ...) set on every engine; the library itself reads no environment variable")
     ap.add_argument("--auc", action="store_true", help="second variant of SURVEY.md 8d: also AUC (dense score rows + ifr_auc_dense)")
     args = ap.parse_args()
     global TOPK

@@ -97,43 +97,45 @@ class HipExactANN(RecommenderBase):
         return ids.cpu().numpy().astype(np.int64), -scores.cpu().numpy()
 
     def rank(self, user_idx, item_indices=None, k=-1, **kwargs):
-        """recom_ann_base.py:100-149: the k nearest items first, everything else after them in index
-        order with score -inf."""
-        if user_idx is None or user_idx < 0 or user_idx >= len(self.user_vectors):
+        """The contract of BaseANN.rank (recom_ann_base.py:100-149): the k nearest items lead the ranking, every other
+        item follows in index order with score -inf; `item_scores` is aligned with `item_indices` (or covers the known
+        items).  One exact fused launch supplies the neighbours."""
+        if user_idx is None or not 0 <= user_idx < len(self.user_vectors):
             raise ScoreException("Can't make score prediction for user %d" % user_idx)
-        knn_items, distances = self.knn_query(self.user_vectors[[user_idx]], k=k)
-        top_k_items, top_k_scores = knn_items[0], -distances[0]
-        item_scores = np.full(self.total_items, -np.inf)
-        item_scores[top_k_items] = top_k_scores
-        all_items = np.arange(self.total_items)
-        ranked_items = np.concatenate([top_k_items, all_items[~np.isin(all_items, top_k_items, assume_unique=True)]])
+        neigh, dist = self.knn_query(self.user_vectors[user_idx][None, :], k=k)
+        head = neigh[0]
+        n_total = self.total_items
+        scores = np.full(n_total, -np.inf)
+        scores[head] = -dist[0]
+        is_head = np.zeros(n_total, bool)
+        is_head[head] = True
+        order = np.concatenate([head, np.flatnonzero(~is_head)])
         if item_indices is None:
-            item_scores = item_scores[: self.num_items]
-            ranked_items = ranked_items[: self.num_items]
-        else:
-            item_scores = item_scores[item_indices]
-            ranked_items = ranked_items[np.isin(ranked_items, item_indices, assume_unique=True)]
-        return ranked_items, item_scores
+            return order[: self.num_items], scores[: self.num_items]
+        wanted = np.zeros(n_total, bool)
+        wanted[np.asarray(item_indices)] = True
+        return order[wanted[order]], scores[item_indices]
 
     def recommend(self, user_id, k=-1, remove_seen=False, train_set=None):
         return self.recommend_batch([user_id], k=k, remove_seen=remove_seen, train_set=train_set)[0]
 
     def recommend_batch(self, batch_users, k=-1, remove_seen=False, train_set=None):
-        """recom_ann_base.py:182-235.  remove_seen drops the user's train ITEMS from the k neighbours
-        (the list may shrink); the reference masks list POSITIONS there (:223-225), which is not
-        reproduced."""
-        user_idx = [self.uid_map.get(uid, -1) for uid in batch_users]
-        if any(i == -1 for i in user_idx):
+        """The batched entry point of recom_ann_base.py:182-235 (same arguments and errors): one fused launch for the
+        whole batch.  remove_seen drops the user's train ITEMS from the k neighbours (the list may shrink); the
+        reference masks list POSITIONS there (:223-225), which is not reproduced."""
+        rows = np.fromiter((self.uid_map.get(uid, -1) for uid in batch_users), np.int64, len(batch_users))
+        if (rows < 0).any():
             raise ValueError(f"{batch_users} is unknown to the model.")
-        if k < -1 or k > self.total_items:
+        if not -1 <= k <= self.total_items:
             raise ValueError(f"k={k} is invalid, there are {self.total_users} users in total.")
-        knn_items, _ = self.knn_query(self.user_vectors[user_idx], k=k)
-        lists = [row for row in knn_items]
-        if remove_seen:
-            if train_set is None:
-                raise ValueError("train_set must be provided to remove seen items.")
-            csr = train_set.csr_matrix
-            lists = [row[~np.isin(row, csr.indices[csr.indptr[u]: csr.indptr[u + 1]])] if u < csr.shape[0] else row
-                     for u, row in zip(user_idx, lists)]
-        item_ids = self.item_ids
-        return [[item_ids[i] for i in row] for row in lists]
+        if remove_seen and train_set is None:
+            raise ValueError("train_set must be provided to remove seen items.")
+        neigh, _ = self.knn_query(self.user_vectors[rows], k=k)
+        raw = np.asarray(self.item_ids, dtype=object)
+        out = []
+        for u, row in zip(rows.tolist(), neigh):
+            if remove_seen and u < train_set.csr_matrix.shape[0]:
+                csr = train_set.csr_matrix
+                row = row[~np.isin(row, csr.indices[csr.indptr[u]: csr.indptr[u + 1]])]
+            out.append(raw[row].tolist())
+        return out

@@ -221,7 +221,9 @@ struct GridPlan { int chunk_tiles, n_chunks, n_utA, chunk_tilesB, n_chunksB; };
 GridPlan plan_grid(ifr_handle h, int64_t n_ut, int64_t S, int min_chunks, int64_t cap_chunks)
 {
     const int64_t T = h->n_tiles;
-    const int64_t max_c = std::max<int64_t>(1, std::min<int64_t>(cap_chunks > 0 ? cap_chunks : 64, T / 16));
+    // both limits apply: at most 64 item chunks (the merge reads 2 lists per chunk from LDS) AND the caller's cap (a
+    // fixed-size workspace: a small batch leaves room for hundreds of chunks, which the merge could not take)
+    const int64_t max_c = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(64, cap_chunks > 0 ? cap_chunks : 64), T / 16));
     auto region = [&](int64_t c, int *tiles, int *chunks) {
         *tiles = (int)((T + c - 1) / c);
         *chunks = (int)((T + *tiles - 1) / *tiles);
@@ -856,13 +858,12 @@ static int rank_topk_item_item(ifr_handle h, const int32_t *user_ids, int64_t n,
     if (rc) return rc;
     p.part_scores = (float *)h->ws_part;
     p.part_ids = (int32_t *)((char *)h->ws_part + entries * 4);
+    if ((size_t)p.n_chunks * KL * 8 > 60000) return fail(h, IFR_ERR_ARG, "ifr_rank_topk: catalogue too large for the merge kernel");
     rc = prof_begin(h, s, &ev);
     if (rc) return rc;
     if (ifr::launch_item_item(p, false, true, s)) return fail(h, IFR_ERR_HIP, "ifr_rank_topk: item-item launch failed");
     rc = prof_end(h, s, ev, (double)n * (double)h->n_items);
     if (rc) return rc;
-    const size_t smem = (size_t)p.n_chunks * KL * 8;
-    if (smem > 60000) return fail(h, IFR_ERR_ARG, "ifr_rank_topk: catalogue too large for the merge kernel");
     if (KL == 16)
         ifr::launch_merge_topk<16>(p.part_scores, p.part_ids, n, p.n_chunks, p.n_chunks, K, out_ids, out_scores, s);
     else
@@ -950,6 +951,8 @@ static int rank_topk_factor(ifr_handle h, const int32_t *user_ids, int64_t n, in
         entries = (size_t)n * n_chunks * 2 * KL;
     }
     const int max_chunks = std::max(n_chunks, n_chunksB);
+    if ((size_t)max_chunks * 2 * KL * 8 > 60000)              // checked BEFORE anything is launched
+        return fail(h, IFR_ERR_ARG, "ifr_rank_topk: too many item chunks for the merge kernel");
     const int64_t gridA = (int64_t)n_utA * n_chunks, grid = gridA + (n_ut - n_utA) * n_chunksB;
     if (grid > (int64_t)0x7fffffff / ifr::BLOCK) return fail(h, IFR_ERR_ARG, "ifr_rank_topk: batch too large, split the user list");
     void *ws = fixed_ws;
@@ -1002,8 +1005,6 @@ static int rank_topk_factor(ifr_handle h, const int32_t *user_ids, int64_t n, in
         h->prof_pairs += (double)n * (double)h->n_items;
     }
     IFR_HIP(h, hipGetLastError());
-    const size_t smem = (size_t)max_chunks * 2 * KL * 8;
-    if (smem > 60000) return fail(h, IFR_ERR_ARG, "ifr_rank_topk: too many item chunks for the merge kernel");
     // one merge per region: a user of region A holds 2 * n_chunks lists, one of region B 2 * n_chunksB
     const int64_t offB = p.part_offB;
     if (KL != 16) return fail(h, IFR_ERR_ARG, "ifr_rank_topk: internal: lane lists are 16 entries");

@@ -94,18 +94,22 @@ class HipScorer:
     def _dev_users(self, x):
         """int32 device tensor of user rows, checked against [0, n_users): the reference indexes its parameter arrays
         with the user index and raises IndexError beyond them; the kernels only clamp.  The check of a device tensor
-        costs one small reduction + sync, skipped when the same tensor (storage, length, version) was checked last."""
+        costs one small reduction + sync, skipped when the same tensor OBJECT (identity, version) was checked last."""
         torch = _torch()
         if self.n_users <= 0:                     # no user side set: the library reports the missing state itself
             return self._dev_i32(x)
         if isinstance(x, torch.Tensor) and x.is_cuda:
             u = x.to(device=self.device, dtype=torch.int32).contiguous()
-            key = (u.data_ptr(), u.numel(), getattr(x, "_version", None), self.n_users)
-            if u.numel() and key != getattr(self, "_users_checked", None):
+            # "the same tensor" = the same Python object at the same version: a storage address alone would also match a
+            # new tensor that the caching allocator placed where a freed, already checked one lived (ADVICE r2)
+            last = getattr(self, "_users_checked", None)
+            same = last is not None and last[0]() is x and last[1:] == (x._version, self.n_users)
+            if u.numel() and not same:
                 lo, hi = (int(v) for v in torch.aminmax(x))
                 if lo < 0 or hi >= self.n_users:
                     raise IndexError(f"user index {lo if lo < 0 else hi} is out of bounds for {self.n_users} user rows")
-                self._users_checked = key
+                import weakref
+                self._users_checked = (weakref.ref(x), x._version, self.n_users)
             return u
         a = np.asarray(x.numpy() if isinstance(x, torch.Tensor) else x)
         if a.size and (int(a.min()) < 0 or int(a.max()) >= self.n_users):

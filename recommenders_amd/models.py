@@ -115,25 +115,39 @@ class RecommenderBase:
         return [os.path.join(save_dir, n) for n in names]
 
     def recommend(self, user_id, k=-1, remove_seen=False, train_set=None):
-        """recommender.py:708-756."""
-        user_idx = self.uid_map.get(user_id, -1)
-        if user_idx == -1:
+        """Top-k raw item ids for one raw user id: the interface (arguments, errors, returned list) of
+        recommender.py:708-756, served by the batched engine.  The reference sorts the whole catalogue for every call
+        (`rank` with k left at -1, :751) and cuts the head afterwards; here a head of up to 1024 items comes from ONE
+        fused / partial-ranking launch over the user's row: `k + |seen|` items are fetched, the seen ones dropped on
+        the host.  Longer lists, k = -1 and users the model cannot score go through `rank` like the reference's.
+        The fast path does not fill `ranked_items` / `item_scores` (a k-item head is not the full ranking they hold)."""
+        if user_id not in self.uid_map:
             raise ValueError(f"{user_id} is unknown to the model.")
-        if k < -1 or k > self.total_items:
+        n_total = self.total_items
+        if not -1 <= k <= n_total:
             raise ValueError(f"k={k} is invalid, there are {self.total_users} users in total.")
-        item_indices = np.arange(self.total_items)
+        u = self.uid_map[user_id]
+        seen = np.zeros(0, np.int64)
         if remove_seen:
-            seen_mask = np.zeros(len(item_indices), dtype="bool")
             if train_set is None:
                 raise ValueError("train_set must be provided to remove seen items.")
-            if user_idx < train_set.csr_matrix.shape[0]:
-                seen_mask[train_set.csr_matrix.getrow(user_idx).indices] = True
-                item_indices = item_indices[~seen_mask]
-        item_rank, _ = self.rank(user_idx, item_indices)
-        if k != -1:
-            item_rank = item_rank[:k]
-        item_ids = self.item_ids
-        return [item_ids[i] for i in item_rank]
+            csr = train_set.csr_matrix
+            if u < csr.shape[0]:
+                seen = np.unique(csr.indices[csr.indptr[u]: csr.indptr[u + 1]])
+        raw_ids = self.item_ids
+        fetch = k + len(seen)
+        if 0 < k and fetch <= min(1024, self.num_items) and hasattr(self, "rank_batch") and self._hip_user_row(u) >= 0:
+            head = self.rank_batch([u], fetch)[0][0]
+            head = head[head >= 0]
+            if len(seen):
+                head = head[~np.isin(head, seen)]
+            if len(head) >= k:                      # (fewer: unknown items would follow -- the full path below)
+                return [raw_ids[i] for i in head[:k].tolist()]
+        cand = np.arange(n_total)
+        if len(seen):
+            cand = np.setdiff1d(cand, seen, assume_unique=True)
+        order = self.rank(u, cand)[0]
+        return [raw_ids[i] for i in (order if k == -1 else order[:k]).tolist()]
 
 
 class HipScoringMixin:
@@ -442,18 +456,19 @@ class ItemItemScoringMixin(HipScoringMixin):
 
 class EASE(ItemItemScoringMixin, RecommenderBase):
     """cornac.models.EASE scoring (cornac/models/ease/recom_ease.py:99-126): s = X[u, :] . B with
-    X = train_set.matrix (:75).  init_params: {'B': [I, I]}; without it `fit` builds B with the
-    reference's closed form (:78-95) -- build="device": Gram scatter + rocSOLVER Cholesky on the GPU
+    X = train_set.matrix (:75).  init_params: {'B': [I, I]} (an already fitted B, e.g. the reference's); without it
+    `fit` builds B on the GPU with the reference's closed form (:78-95): Gram scatter + rocSOLVER Cholesky
     (ifr_fit_ease; B goes straight into the scoring engine, `self.B` is its float64 host copy up to
-    `device_B_copy_max_items` items and None above), build="host": the reference's NumPy expressions.
-    precision="f64" keeps B in float64 on the device and sums every score in float64 in history order, the
-    reference's arithmetic (`score` then agrees with it to a few ulp of float64; rankings use that sum rounded
-    once to fp32); the default "f32" halves the bytes the HBM-bound scoring kernel reads."""
+    `device_B_copy_max_items` items and None above).  There is no host build in this package (the NumPy restatement
+    of the closed form is test infrastructure: the checker of tests/test_gpu_fit.py).
+    precision="f64" keeps B in float64 on the device, sums every score in float64 in history order -- the
+    reference's arithmetic -- and RANKS those float64 sums (64-bit keys); the default "f32" halves the bytes the
+    HBM-bound scoring kernel reads."""
 
     device_B_copy_max_items = 16384          # 2 GiB of float64 on the host
 
     def __init__(self, name="EASEᴿ", lamb=500, posB=True, trainable=True, verbose=True, seed=None, B=None, U=None,
-                 init_params=None, build="device", precision="f32", **kwargs):
+                 init_params=None, precision="f32", **kwargs):
         RecommenderBase.__init__(self, name=name, trainable=trainable, verbose=verbose)
         self.lamb, self.posB, self.seed = lamb, posB, seed
         if precision not in ("f32", "f64"):
@@ -461,9 +476,6 @@ class EASE(ItemItemScoringMixin, RecommenderBase):
         self.precision = precision
         self.B = B if B is not None else (init_params or {}).get("B")
         self.U = U
-        if build not in ("device", "host"):
-            raise ValueError("build must be 'device' or 'host'")
-        self.build = build
 
     def fit(self, train_set, val_set=None):
         import scipy.sparse as sp
@@ -473,32 +485,22 @@ class EASE(ItemItemScoringMixin, RecommenderBase):
         if self.B is None:
             if not self.trainable:
                 raise ValueError("EASE(trainable=False) needs init_params={'B': ...}")
-            if self.build == "device":
-                from .engine import HipScorer
-                X = sp.csr_matrix(self.U)
-                X.sum_duplicates()
-                X.sort_indices()
-                eng = HipScorer(self.hip_device)
-                try:
-                    n_items = X.shape[1]
-                    self.B = eng.fit_ease(X.indptr.astype(np.int64), X.indices.astype(np.int32), X.data.astype(np.float32),
-                                          n_items, self.lamb, self.posB, want_B=n_items <= self.device_B_copy_max_items,
-                                          precision=self.precision)
-                    self._hip_set_histories(eng, X)
-                except Exception:
-                    eng.close()
-                    raise
-                self._hip = eng                                     # B is already resident: no second upload
-                return self
-            G = self.U.T.dot(self.U).toarray()                      # :78
-            di = np.diag_indices(G.shape[0])
-            G[di] = G.diagonal() + self.lamb
-            P = np.linalg.inv(G)
-            B = P / (-np.diag(P))
-            B[di] = 0.0
-            if self.posB:
-                B[B < 0] = 0
-            self.B = B
+            from .engine import HipScorer
+            X = sp.csr_matrix(self.U)
+            X.sum_duplicates()
+            X.sort_indices()
+            eng = HipScorer(self.hip_device)
+            try:
+                n_items = X.shape[1]
+                self.B = eng.fit_ease(X.indptr.astype(np.int64), X.indices.astype(np.int32), X.data.astype(np.float32),
+                                      n_items, self.lamb, self.posB, want_B=n_items <= self.device_B_copy_max_items,
+                                      precision=self.precision)
+                self._hip_set_histories(eng, X)
+            except Exception:
+                eng.close()
+                raise
+            eng.row0 = 0
+            self._hip = eng                                     # B is already resident: no second upload
         return self
 
     def _hip_item_model(self):
@@ -515,61 +517,55 @@ class RP3_Beta(ItemItemScoringMixin, RecommenderBase):
     """cornac.models.RP3_Beta scoring (cornac/models/rp3_beta/recom_rp3beta.py:99-131,
     graph_recommender.py:87-117): s = P3[u, items] / deg(item)^beta, evaluated in item-item form
     s = (P_ui[u, :] . W) * deg^-beta with W = P_iu . P_ui, so the (U+I)^2 cube P3 is never built.
-    `fit` builds P_ui, W and the degrees from the binarised train matrix (rating > 0, :76): build="device"
-    through ifr_fit_rp3beta (counting-sort transpose + rocSPARSE SpGEMM, W stays on the device), build="host"
-    (and any dense item matrix) with SciPy like the reference.
-    item_matrix: "csr" | "dense" | "auto" (dense below 8192 items)."""
+    `fit` builds P_ui, W and the degrees from the binarised train matrix (rating > 0, :76) on the GPU
+    (ifr_fit_rp3beta: counting-sort transpose + rocSPARSE SpGEMM pattern + ordered float64 sums; W stays on the
+    device as the CSR item matrix).  init_params = {'P_ui': csr [U, I], 'W': csr [I, I], 'item_degrees': int [I]}
+    installs arrays built elsewhere instead (item_matrix "csr" | "dense" | "auto": dense below 8192 items); there is
+    no host build in this package (the SciPy restatement is test infrastructure, the checker of the tests)."""
 
-    def __init__(self, beta=0.7, name="RP3_beta", trainable=True, verbose=False, item_matrix="auto", build="device", **kwargs):
+    def __init__(self, beta=0.7, name="RP3_beta", trainable=True, verbose=False, item_matrix="auto", init_params=None,
+                 **kwargs):
         RecommenderBase.__init__(self, name=name, trainable=trainable, verbose=verbose)
         self.beta = beta
         self.item_matrix = item_matrix
-        if build not in ("device", "host"):
-            raise ValueError("build must be 'device' or 'host'")
-        self.build = build
-        self.P_ui = self.W = self.item_degrees = None
+        ip = init_params or {}
+        self.P_ui, self.W, self.item_degrees = ip.get("P_ui"), ip.get("W"), ip.get("item_degrees")
+        if (self.W is None) != (self.P_ui is None) or (self.W is None) != (self.item_degrees is None):
+            raise ValueError("RP3_Beta init_params needs all of 'P_ui', 'W' and 'item_degrees'")
 
     def fit(self, train_set, val_set=None):
         import scipy.sparse as sp
         RecommenderBase.fit(self, train_set)
-        A = sp.csr_matrix(train_set.csr_matrix, dtype=np.float64, copy=True)   # never write into the data set
-        A.data[:] = (A.data > 0).astype(np.float64)                  # recom_rp3beta.py:73-93
+        self.hip_invalidate()
+        if self.W is not None:                                        # arrays built elsewhere: uploaded on first use
+            return self
+        if self.item_matrix == "dense":
+            raise ValueError("RP3_Beta: the device build keeps W as a CSR matrix; pass init_params for a dense W")
+        A = sp.csr_matrix(train_set.csr_matrix, dtype=np.float32, copy=True)    # never write into the data set
+        A.data[:] = (A.data > 0).astype(np.float32)                  # recom_rp3beta.py:73-93
         A.eliminate_zeros()
         A.sum_duplicates()
         A.sort_indices()
-        self.hip_invalidate()
-        self.item_degrees = A.getnnz(axis=0).astype(np.int64)        # :67
-        if self.build == "device" and self.item_matrix != "dense":
-            # W = P_iu . P_ui, P_ui and 1/deg^beta are built and installed by ifr_fit_rp3beta; W stays on the device
-            from .engine import HipScorer
-            eng = HipScorer(self.hip_device)
-            try:
-                self.w_nnz = eng.fit_rp3beta(A.indptr.astype(np.int64), A.indices.astype(np.int32), A.shape[1], self.beta)
-            except Exception:
-                eng.close()
-                raise
-            self.P_ui = self.W = None
-            self._hip_zero_row = max(int(self.total_users or 0), A.shape[0])
-            self._hip = eng
-            return self
-        du = np.asarray(A.sum(axis=1)).ravel()
-        di = np.asarray(A.sum(axis=0)).ravel()
-        du[du == 0] = 0.0001                                          # graph_recommender.py:54
-        di[di == 0] = 0.0001
-        self.P_ui = (sp.diags(1.0 / du) @ A).tocsr()
-        P_iu = (sp.diags(1.0 / di) @ A.T).tocsr()
-        self.W = (P_iu @ self.P_ui).tocsr()
-        self.W.sort_indices()
+        from .engine import HipScorer
+        eng = HipScorer(self.hip_device)
+        try:
+            self.w_nnz = eng.fit_rp3beta(A.indptr.astype(np.int64), A.indices.astype(np.int32), A.shape[1], self.beta)
+        except Exception:
+            eng.close()
+            raise
+        self._hip_zero_row = max(int(self.total_users or 0), A.shape[0])
+        eng.row0 = 0
+        self._hip = eng
         return self
 
     def _hip_item_model(self):
         if self.W is None:
             raise RuntimeError("RP3_Beta: W was built on the device and went with the engine that hip_invalidate() "
-                               "closed -- call fit() again (or fit with build='host')")
+                               "closed -- call fit() again")
         # the reference keeps the degrees in an int array, so its 0.0001 guard stores 0 and a
         # zero-degree item scores 0 * inf = nan (graph_recommender.py:107-115); same here
         with np.errstate(divide="ignore"):
-            pen = (1.0 / (self.item_degrees.astype(np.float64) ** self.beta)).astype(np.float32)
+            pen = (1.0 / (np.asarray(self.item_degrees).astype(np.float64) ** self.beta)).astype(np.float32)
         mode = self.item_matrix
         if mode == "auto":
             mode = "dense" if self.W.shape[0] <= 8192 else "csr"
@@ -602,7 +598,7 @@ def wrap_reference_model(model, device=0):
         out = EASE(name=model.name, lamb=model.lamb, posB=model.posB, B=model.B, U=model.U, trainable=False)
     elif name == "RP3_Beta":
         out = RP3_Beta(beta=model.beta, name=model.name)
-        out.fit(model.train_set)
+        out.fit(model.train_set)                 # item-item form built on the device from the same train matrix
     else:
         raise TypeError(f"no HIP scoring facade for {name}")
     for attr in ("num_users", "num_items", "uid_map", "iid_map", "min_rating", "max_rating", "global_mean",

@@ -388,6 +388,14 @@ def test_user_indices_outside_the_model_raise_like_the_reference(toy):
             eng.rank_topk(ids, 5)
         with pytest.raises(IndexError):
             eng.score_dense(ids)
+    # a checked tensor is freed, the allocator hands its block to a new tensor with a bad id -- the range
+    # check must run again (it is keyed on the tensor object, not on the storage address)
+    good = torch.arange(64, dtype=torch.int32, device=eng.device)
+    eng.rank_topk(good, 5)
+    del good
+    bad_ids = torch.full((64,), eng.n_users + 3, dtype=torch.int32, device=eng.device)
+    with pytest.raises(IndexError):
+        eng.rank_topk(bad_ids, 5)
     mf = _model(d, "mf", train_set)          # MF: an unknown user keeps mu + Bi whatever the index (recom_mf.py:277-280)
     np.testing.assert_array_equal(mf.score(10 ** 7), mf.score(mf.num_users + 1))
 

@@ -215,7 +215,10 @@ def _facade(d, name, train_set, form):
     if name == "ease":
         return EASE(lamb=50, trainable=False, init_params={"B": d["ease_B"]},
                     precision="f64" if form == "dense_f64" else "f32").fit(train_set)
-    return RP3_Beta(beta=float(d["rp3_beta"]), item_matrix=form).fit(train_set)
+    # the item-item arrays of the oracle's restatement of graph_recommender.py:24-55 (pinned by the reference's scores)
+    P_ui, W, deg = orc.rp3_item_item(sp.csr_matrix((_csr(d, "train") > 0).astype(np.float64)))
+    return RP3_Beta(beta=float(d["rp3_beta"]), item_matrix=form,
+                    init_params={"P_ui": P_ui, "W": W, "item_degrees": deg}).fit(train_set)
 
 
 @pytest.mark.parametrize("name,form", [("ease", "dense"), ("ease", "dense_f64"), ("rp3", "dense"), ("rp3", "csr")])

@@ -277,25 +277,25 @@ def test_lazy_cache_and_cache_rankings():
     assert isinstance(pickle.loads(pickle.dumps(m.ranked_items)), dict)
 
 
-def test_rp3_fit_builds_item_item_form_and_leaves_the_dataset_alone(toy):
-    """RP3_Beta.fit (host model-build step): P_ui / W / degrees equal the restatement of
-    graph_recommender.py:24-55 pinned by the reference's scores, and the train set is not modified."""
-    from recommenders_amd.models import EASE, RP3_Beta
+def test_rp3_facade_hands_prebuilt_arrays_to_the_engine_unchanged(toy):
+    """RP3_Beta(init_params=...): arrays built elsewhere (here: the oracle's restatement of graph_recommender.py:24-55,
+    pinned by the reference's scores) reach the engine as fp32 W / P_ui / 1/deg^beta, and the train set is not
+    modified.  (The package itself has no host build: `fit` without init_params runs ifr_fit_rp3beta on the GPU.)"""
+    from recommenders_amd.models import RP3_Beta
     d = toy
     train_set, _, _ = _datasets(d)
     before = train_set.csr_matrix.data.copy()
-    m = RP3_Beta(beta=float(d["rp3_beta"]), build="host").fit(train_set)
-    np.testing.assert_array_equal(train_set.csr_matrix.data, before)
     A_bin = sp.csr_matrix((_csr(d, "train") > 0).astype(np.float64))
+    P_ui, W, deg = orc.rp3_item_item(A_bin)
+    m = RP3_Beta(beta=float(d["rp3_beta"]), init_params={"P_ui": P_ui, "W": W, "item_degrees": deg}).fit(train_set)
+    np.testing.assert_array_equal(train_set.csr_matrix.data, before)
     P32, W32, pen = orc.rp3_model_arrays(A_bin, float(d["rp3_beta"]))
     M, hist, col_scale = m._hip_item_model()
     np.testing.assert_array_equal(hist.toarray(), P32.toarray())
     np.testing.assert_array_equal(np.asarray(M), W32.toarray())
     np.testing.assert_array_equal(col_scale, pen)
-    # EASE.fit: the closed form of recom_ease.py:78-95 reproduces the reference's B
-    e = EASE(lamb=50, posB=True, trainable=True, build="host").fit(train_set)
-    np.testing.assert_allclose(e.B, d["ease_B"], rtol=1e-9, atol=1e-12)
-    np.testing.assert_array_equal(train_set.csr_matrix.data, before)
+    with pytest.raises(ValueError):
+        RP3_Beta(init_params={"W": W})
 
 
 @pytest.mark.parametrize("model", ["mf", "bpr"])

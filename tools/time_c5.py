@@ -1,4 +1,4 @@
-"""Dev: time the CSR top-K kernel alone on the C5 workload (IFR_DEBUG_MODE ablations change results)."""
+"""Dev: time the CSR top-K kernel alone on the C5 workload (debug_mode ablations change results)."""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
