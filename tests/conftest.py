@@ -25,6 +25,14 @@ def toy():
 
 
 @pytest.fixture(scope="session")
+def gap():
+    """Gap-guaranteed reference outputs for all five models (tests/golden/make_golden.py::make_gap): per model a test
+    split that only holds users whose decisive reference scores are separated by > 1e-4 relative, so parity tests
+    assert on every evaluated user."""
+    return load_golden("gap_all_models.npz")
+
+
+@pytest.fixture(scope="session")
 def c1():
     return load_golden("c1_bpr_ml100k_shape.npz")
 

@@ -94,28 +94,26 @@ def test_build_eval_csrs_matches_reference_rule(toy):
 
 
 @pytest.mark.parametrize("model", ["bpr", "mf", "wmf"])
-def test_ranking_eval_host_logic_against_reference(toy, model):
-    d = toy
-    train_set, test_set, val_set = _datasets(d)
+def test_ranking_eval_host_logic_against_reference(gap, model):
+    """The facade's host logic (candidate sets, metric plan, aggregation) on the CPU stand-in engine against the
+    reference's ranking_eval on the gap-guaranteed fixture: EVERY evaluated user, per-user values to 1e-9, means to
+    1e-6 (the north-star bar), no tie filter."""
+    d = gap
+    train_set, _, val_set = _datasets(d)
+    test_set = Dataset.from_csr(_csr(d, f"{model}__test"))
     fake_model = types.SimpleNamespace(is_fitted=True)
     eng = _engine(d, model, test_set.num_users)
     mets = _spec_objects(d)
     avg, per = ifr_eval.ranking_eval(fake_model, mets, train_set, test_set, val_set,
                                      rating_threshold=float(d["rating_threshold"]), exclude_unknowns=True, _engine=eng)
     users = d[f"{model}__users"]
-    assert sorted(per[0].keys()) == users.tolist()
+    assert sorted(per[0].keys()) == users.tolist() and len(users) > 300
     ref = d[f"{model}__per_user"]
-    ref_hs = d[f"{model}__ranked_head_scores"]
-    gaps = np.abs(np.diff(ref_hs, axis=1))
-    tie_free = (gaps > 1e-5 * np.maximum(1e-3, np.abs(ref_hs[:, :-1]))).all(axis=1)
     for j in range(len(mets)):
         got = np.asarray([per[j][int(u)] for u in users])
-        if mets[j].name == "AUC":
-            assert np.abs(got - ref[:, j]).max() < 1e-4
-        else:
-            np.testing.assert_allclose(got[tie_free], ref[tie_free][:, j], atol=1e-9, rtol=0)
+        np.testing.assert_allclose(got, ref[:, j], atol=1e-9, rtol=0)
         assert avg[j] == pytest.approx(got.mean(), abs=1e-12)
-    np.testing.assert_allclose(avg, d[f"{model}__avg"], atol=2e-4, rtol=0)
+    np.testing.assert_allclose(avg, d[f"{model}__avg"], atol=1e-6, rtol=0)
 
 
 def test_ranking_eval_full_list_metrics_and_errors(toy):
@@ -151,7 +149,7 @@ def test_ranking_eval_full_list_metrics_and_errors(toy):
 def test_list_metrics_host_logic_against_reference(list_metrics):
     """k = -1 / 50 / 100 / 200 cut-offs, MRR, MAP, NCRR, HitRatio, FMeasure through ranking_eval's list route:
     the reference's own per-user values (fixture made by the reference's ranking_eval)."""
-    from conftest import metric_objects, positives_clear
+    from conftest import metric_objects
     d = list_metrics
     train_set, test_set, _ = _datasets(d)
     eng = _engine(d, "bpr", test_set.num_users)
@@ -160,17 +158,11 @@ def test_list_metrics_host_logic_against_reference(list_metrics):
     avg, per = ifr_eval.ranking_eval(types.SimpleNamespace(is_fitted=True), mets, train_set, test_set,
                                      rating_threshold=thr, exclude_unknowns=True, _engine=eng)
     users, ref = d["bpr__users"], d["bpr__per_user"]
-    assert sorted(per[0].keys()) == users.tolist()
-    train, test = _csr(d, "train"), _csr(d, "test")
-    clear = []
-    for u in users:
-        cand, pos, _ = orc.eval_sets(train, test, None, int(u), thr, ni, test.shape[1], True)
-        clear.append(positives_clear(orc.score_bpr(d["bpr_U"], d["bpr_V"], d["bpr_Bi"], int(u)), cand, pos))
-    clear = np.asarray(clear)
-    assert clear.mean() > 0.8
+    assert sorted(per[0].keys()) == users.tolist() and len(users) > 150
+    # gap-guaranteed fixture: every user, no filter
     got = np.asarray([[per[j][int(u)] for j in range(len(mets))] for u in users])
-    np.testing.assert_allclose(got[clear], ref[clear], rtol=0, atol=1e-9)
-    np.testing.assert_allclose(avg, d["bpr__avg"], atol=5e-4, rtol=0)
+    np.testing.assert_allclose(got, ref, rtol=0, atol=1e-9)
+    np.testing.assert_allclose(avg, d["bpr__avg"], atol=1e-6, rtol=0)
 
 
 def test_candidate_pools_are_the_heads_of_the_cached_rankings(toy):
@@ -312,17 +304,12 @@ def test_ranking_eval_with_unknown_items_and_users(unknowns, model):
                                      rating_threshold=float(d["rating_threshold"]), exclude_unknowns=False, _engine=eng)
     users = d[f"{model}__users"]
     assert sorted(per[0].keys()) == users.tolist()
-    ref, hs = d[f"{model}__per_user"], d[f"{model}__ranked_head_scores"]
-    gaps = np.abs(np.diff(hs, axis=1))
-    tie_free = (gaps > 1e-5 * np.maximum(1e-3, np.abs(hs[:, :-1]))).all(axis=1)
-    assert tie_free.mean() > 0.7
-    for j in range(len(mets)):
+    ref = d[f"{model}__per_user"]
+    assert len(users) > 80
+    for j in range(len(mets)):                      # gap-guaranteed fixture: every user, no filter
         got = np.asarray([per[j][int(u)] for u in users])
-        if mets[j].name == "AUC":
-            assert np.abs(got - ref[:, j]).max() < 1e-4
-        else:
-            np.testing.assert_allclose(got[tie_free], ref[tie_free][:, j], atol=1e-9, rtol=0)
-    np.testing.assert_allclose(avg, d[f"{model}__avg"], atol=5e-4, rtol=0)
+        np.testing.assert_allclose(got, ref[:, j], atol=1e-9, rtol=0)
+    np.testing.assert_allclose(avg, d[f"{model}__avg"], atol=1e-6, rtol=0)
 
 
 def test_append_unknown_items_fills_short_lists():
