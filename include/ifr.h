@@ -96,10 +96,14 @@ int ifr_set_item_matrix_csr(ifr_handle h, const int64_t *indptr, const int32_t *
                             int64_t n_items, int64_t nnz, const float *col_scale);
 
 /* The fp64 option of the dense item matrix (the reference scores EASE in float64: B from np.linalg.inv on float64,
- * recom_ease.py:78-95, score X[u, :].dot(B), :123-124): M [n_items][ld] row-major fp64 is kept in fp64 on the device and
- * every (user, item) sum is one fp64 fma chain over the history row in CSR order, times col_scale in fp64.
- * ifr_score_dense_f64 returns those sums; ifr_rank_topk, ifr_score_dense and everything downstream round them once
- * to fp32 and rank that.  Twice the bytes of the fp32 matrix per user (the path is HBM-bound). */
+ * recom_ease.py:78-95, score X[u, :].dot(B), :123-124, and orders those float64 values, recommender.py:643-652):
+ * M [n_items][ld] row-major fp64 is kept in fp64 on the device and every (user, item) sum is one fp64 fma chain over
+ * the history row in CSR order, times col_scale in fp64.  ifr_score_dense_f64 returns those sums.  ifr_rank_topk RANKS
+ * the fp64 sums themselves (64-bit order-preserving keys through the selection and the merge; the scores it returns
+ * are the winners' sums rounded to fp32 afterwards), and the *_f64 consumers of dense rows below (ifr_select_topk_f64,
+ * ifr_rank_full_f64, ifr_rank_items_f64, ifr_auc_dense_f64, ifr_eval_dense_metrics_f64) take the fp64 rows
+ * unrounded.  ifr_score_dense still writes fp32 rows (the sums rounded once).  Twice the bytes of the fp32 matrix per
+ * user (the path is HBM-bound). */
 int ifr_set_item_matrix_dense_f64(ifr_handle h, const double *M, int64_t n_items, int64_t ld, const float *col_scale);
 /* out: dev [n][ld] fp64, ld >= n_items; IFR_ERR_STATE unless the item matrix is an fp64 one. */
 int ifr_score_dense_f64(ifr_handle h, const int32_t *user_ids, int64_t n, double *out, int64_t ld, void *stream);
@@ -265,6 +269,23 @@ int ifr_rank_items(ifr_handle h, const float *scores, int64_t n_scores, const in
  * out_ids / out_scores: dev [n][K], rows with fewer than K candidates end in -1 / -inf. */
 int ifr_select_topk(ifr_handle h, const int32_t *user_ids, int64_t n, const float *scores, int64_t ld, int K, int32_t *out_ids,
                     float *out_scores, void *stream);
+
+/* The consumers of dense score rows for fp64 rows (as written by ifr_score_dense_f64): the reference ranks the float64
+ * scores of EASE / RP3-beta directly (cornac/models/recommender.py:643-652 on recom_ease.py:123-124 /
+ * graph_recommender.py:104-117 outputs), so these order 64-bit keys of the doubles -- score descending, item index
+ * ascending, nothing rounded before it is ranked.  Arguments, outputs and limits as their fp32 namesakes
+ * (ifr_select_topk: out_scores are the selected sums rounded to fp32; ifr_eval_dense_metrics_f64: rows with up to 2048
+ * positives; ifr_auc_dense_f64: up to 4096), scores: dev [n][ld] fp64. */
+int ifr_select_topk_f64(ifr_handle h, const int32_t *user_ids, int64_t n, const double *scores, int64_t ld, int K, int32_t *out_ids,
+                        float *out_scores, void *stream);
+int ifr_rank_full_f64(ifr_handle h, const int32_t *user_ids, int64_t n, const double *scores, int64_t ld, int32_t *out_ids,
+                      int32_t *n_cand, void *stream);
+int ifr_rank_items_f64(ifr_handle h, const double *scores, int64_t n_scores, const int32_t *items, int64_t m, int32_t *out_ids,
+                       void *stream);
+int ifr_auc_dense_f64(ifr_handle h, const int32_t *user_ids, int64_t n, const double *scores, int64_t ld, double *out_auc, void *stream);
+int ifr_eval_dense_metrics_f64(ifr_handle h, const int32_t *user_ids, int64_t n, const double *scores, int64_t ld, const int32_t *ks,
+                               int n_k, double *out_per_user, int32_t *evaluated, double *out_sums, void *stream);
+int ifr_pad_scores_min_f64(ifr_handle h, double *scores, int64_t n, int64_t ld, void *stream);
 
 /* Items unknown to the model (evaluation with exclude_unknowns = False, cornac/eval_methods/
  * base_method.py:262-279): after ifr_set_option(h, "catalogue_items", N) with N > n_items,

@@ -28,6 +28,12 @@ SIGNATURES = {
     "ifr_set_item_matrix_dense": (ctypes.c_int, [vp, vp, ctypes.c_int64, ctypes.c_int64, vp]),
     "ifr_set_item_matrix_dense_f64": (ctypes.c_int, [vp, vp, ctypes.c_int64, ctypes.c_int64, vp]),
     "ifr_score_dense_f64": (ctypes.c_int, [vp, vp, ctypes.c_int64, vp, ctypes.c_int64, vp]),
+    "ifr_select_topk_f64": (ctypes.c_int, [vp, vp, ctypes.c_int64, vp, ctypes.c_int64, ctypes.c_int, vp, vp, vp]),
+    "ifr_rank_full_f64": (ctypes.c_int, [vp, vp, ctypes.c_int64, vp, ctypes.c_int64, vp, vp, vp]),
+    "ifr_rank_items_f64": (ctypes.c_int, [vp, vp, ctypes.c_int64, vp, ctypes.c_int64, vp, vp]),
+    "ifr_auc_dense_f64": (ctypes.c_int, [vp, vp, ctypes.c_int64, vp, ctypes.c_int64, vp, vp]),
+    "ifr_eval_dense_metrics_f64": (ctypes.c_int, [vp, vp, ctypes.c_int64, vp, ctypes.c_int64, vp, ctypes.c_int, vp, vp, vp, vp]),
+    "ifr_pad_scores_min_f64": (ctypes.c_int, [vp, vp, ctypes.c_int64, ctypes.c_int64, vp]),
     "ifr_eval_dense_metrics": (ctypes.c_int, [vp, vp, ctypes.c_int64, vp, ctypes.c_int64, vp, ctypes.c_int, vp, vp, vp, vp]),
     "ifr_select_topk": (ctypes.c_int, [vp, vp, ctypes.c_int64, vp, ctypes.c_int64, ctypes.c_int, vp, vp, vp]),
     "ifr_fit_rp3beta": (ctypes.c_int, [vp, vp, vp, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_double, vp]),

@@ -27,6 +27,19 @@ int launch_rank_items(const float *scores, int64_t n_scores, const int32_t *item
 int launch_select_topk(const float *scores, int64_t ld, const int32_t *user_ids, int64_t n, int n_items, const int64_t *ex_ptr,
                        const int32_t *ex_idx, int64_t ex_rows, int K, int32_t *out_ids, float *out_scores, hipStream_t stream);
 int select_topk_max_k();
+// fp64 score rows (item-item models scored in float64): the same consumers on 64-bit keys
+int launch_auc_f64(const double *scores, int64_t ld, const int32_t *user_ids, int64_t n, int n_items,
+                   const int64_t *ex_ptr, const int32_t *ex_idx, int64_t ex_rows,
+                   const int64_t *tr_ptr, const int32_t *tr_idx, int64_t tr_rows, int max_pos, double *out, hipStream_t stream);
+int auc_max_pos_f64();
+int launch_rank_items_f64(const double *scores, int64_t n_scores, const int32_t *items, int64_t m, int32_t *out_ids,
+                          void **ws, size_t *ws_bytes, hipStream_t stream);
+int launch_select_topk_f64(const double *scores, int64_t ld, const int32_t *user_ids, int64_t n, int n_items, const int64_t *ex_ptr,
+                           const int32_t *ex_idx, int64_t ex_rows, int K, int32_t *out_ids, float *out_scores, hipStream_t stream);
+int launch_rank_full_f64(const double *scores, int64_t ld, const int32_t *user_ids, int64_t n, int n_items,
+                         const int64_t *ex_ptr, const int32_t *ex_idx, int64_t ex_rows,
+                         int32_t *out_ids, int32_t *n_cand, void **ws, size_t *ws_bytes, hipStream_t stream);
+int launch_pad_rows_min_f64(double *scores, int64_t n, int64_t ld, int n_known, int n_cat, hipStream_t stream);
 int launch_rank_full(const float *scores, int64_t ld, const int32_t *user_ids, int64_t n, int n_items,
                      const int64_t *ex_ptr, const int32_t *ex_idx, int64_t ex_rows,
                      int32_t *out_ids, int32_t *n_cand, void **ws, size_t *ws_bytes, hipStream_t stream);
@@ -854,17 +867,27 @@ static int rank_topk_item_item(ifr_handle h, const int32_t *user_ids, int64_t n,
         return prof_end(h, s, ev, (double)n * (double)h->n_items);
     }
     const size_t entries = (size_t)n * p.n_chunks * KL;
-    rc = grow(h, &h->ws_part, &h->ws_part_bytes, entries * 8);
+    const bool f64 = h->iiM64 != nullptr;             // fp64 option: the lists carry the fp64 sums and are ranked on them
+    rc = grow(h, &h->ws_part, &h->ws_part_bytes, entries * (f64 ? 12 : 8));
     if (rc) return rc;
-    p.part_scores = (float *)h->ws_part;
-    p.part_ids = (int32_t *)((char *)h->ws_part + entries * 4);
+    if (f64) {
+        p.part_scores64 = (double *)h->ws_part;
+        p.part_ids = (int32_t *)((char *)h->ws_part + entries * 8);
+    } else {
+        p.part_scores = (float *)h->ws_part;
+        p.part_ids = (int32_t *)((char *)h->ws_part + entries * 4);
+    }
+    if (f64 && (size_t)p.n_chunks * KL * 12 > 60000) return fail(h, IFR_ERR_ARG, "ifr_rank_topk: catalogue too large for the merge kernel");
     if ((size_t)p.n_chunks * KL * 8 > 60000) return fail(h, IFR_ERR_ARG, "ifr_rank_topk: catalogue too large for the merge kernel");
     rc = prof_begin(h, s, &ev);
     if (rc) return rc;
     if (ifr::launch_item_item(p, false, true, s)) return fail(h, IFR_ERR_HIP, "ifr_rank_topk: item-item launch failed");
     rc = prof_end(h, s, ev, (double)n * (double)h->n_items);
     if (rc) return rc;
-    if (KL == 16)
+    if (f64) {
+        if (ifr::launch_merge_topk_f64(p.part_scores64, p.part_ids, n, p.n_chunks, KL, K, out_ids, out_scores, s))
+            return fail(h, IFR_ERR_HIP, "ifr_rank_topk: fp64 merge launch failed");
+    } else if (KL == 16)
         ifr::launch_merge_topk<16>(p.part_scores, p.part_ids, n, p.n_chunks, p.n_chunks, K, out_ids, out_scores, s);
     else
         ifr::launch_merge_topk<32>(p.part_scores, p.part_ids, n, p.n_chunks, p.n_chunks, K, out_ids, out_scores, s);
@@ -1208,8 +1231,8 @@ int ifr_eval_ranked_metrics(ifr_handle h, const int32_t *user_ids, int64_t n, co
     return sum_columns(h, out_per_user, evaluated, n, IFR_METRICS_PER_K * n_k + 2, out_sums, s);
 }
 
-int ifr_eval_dense_metrics(ifr_handle h, const int32_t *user_ids, int64_t n, const float *scores, int64_t ld, const int32_t *ks,
-                           int n_k, double *out_per_user, int32_t *evaluated, double *out_sums, void *stream)
+static int eval_dense_metrics_any(ifr_handle h, const int32_t *user_ids, int64_t n, const void *scores, bool f64, int64_t ld,
+                                  const int32_t *ks, int n_k, double *out_per_user, int32_t *evaluated, double *out_sums, void *stream)
 {
     if (!h) return IFR_ERR_ARG;
     if (!h->tr_ptr) return fail(h, IFR_ERR_STATE, "ifr_eval_dense_metrics: truth CSR not set");
@@ -1219,8 +1242,9 @@ int ifr_eval_dense_metrics(ifr_handle h, const int32_t *user_ids, int64_t n, con
     if (n_k < 1 || n_k > ifr::MAX_KS) return fail(h, IFR_ERR_ARG, "ifr_eval_dense_metrics: n_k in [1,8]");
     for (int q = 0; q < n_k; ++q)
         if (ks[q] == 0 || ks[q] < -1) return fail(h, IFR_ERR_ARG, "ifr_eval_dense_metrics: cut-off must be -1 or > 0");
-    if (h->tr_max_row > ifr::DM_MAX_POS)
-        return fail(h, IFR_ERR_ARG, "ifr_eval_dense_metrics: more than 4096 positives in one row (use ifr_rank_full + ifr_eval_ranked_metrics)");
+    if (h->tr_max_row > (f64 ? ifr::DM_MAX_POS_F64 : ifr::DM_MAX_POS))
+        return fail(h, IFR_ERR_ARG, f64 ? "ifr_eval_dense_metrics_f64: more than 2048 positives in one row (use ifr_rank_full_f64 + ifr_eval_ranked_metrics)"
+                                        : "ifr_eval_dense_metrics: more than 4096 positives in one row (use ifr_rank_full + ifr_eval_ranked_metrics)");
     if (n > (int64_t)0xffffffffu / ifr::BLOCK) return fail(h, IFR_ERR_ARG, "ifr_eval_dense_metrics: batch too large");
     IFR_HIP(h, hipSetDevice(h->device));
     hipStream_t s = (hipStream_t)stream;
@@ -1233,9 +1257,95 @@ int ifr_eval_dense_metrics(ifr_handle h, const int32_t *user_ids, int64_t n, con
     int cap = 32;
     while (cap < h->tr_max_row) cap <<= 1;
     p.cap = cap;
-    hipLaunchKernelGGL(ifr::metrics_dense_kernel, dim3((unsigned)n), dim3(ifr::BLOCK), (size_t)cap * 12 + 16, s, p);
+    if (f64) hipLaunchKernelGGL(ifr::metrics_dense_kernel<double>, dim3((unsigned)n), dim3(ifr::BLOCK), (size_t)cap * 20 + 16, s, p);
+    else hipLaunchKernelGGL(ifr::metrics_dense_kernel<float>, dim3((unsigned)n), dim3(ifr::BLOCK), (size_t)cap * 12 + 16, s, p);
     IFR_HIP(h, hipGetLastError());
     return sum_columns(h, out_per_user, evaluated, n, IFR_METRICS_PER_K * n_k + 2, out_sums, s);
+}
+
+int ifr_eval_dense_metrics(ifr_handle h, const int32_t *user_ids, int64_t n, const float *scores, int64_t ld, const int32_t *ks,
+                           int n_k, double *out_per_user, int32_t *evaluated, double *out_sums, void *stream)
+{
+    return eval_dense_metrics_any(h, user_ids, n, scores, false, ld, ks, n_k, out_per_user, evaluated, out_sums, stream);
+}
+
+int ifr_eval_dense_metrics_f64(ifr_handle h, const int32_t *user_ids, int64_t n, const double *scores, int64_t ld, const int32_t *ks,
+                               int n_k, double *out_per_user, int32_t *evaluated, double *out_sums, void *stream)
+{
+    return eval_dense_metrics_any(h, user_ids, n, scores, true, ld, ks, n_k, out_per_user, evaluated, out_sums, stream);
+}
+
+int ifr_rank_items_f64(ifr_handle h, const double *scores, int64_t n_scores, const int32_t *items, int64_t m, int32_t *out_ids,
+                       void *stream)
+{
+    if (!h) return IFR_ERR_ARG;
+    if (m == 0) return IFR_OK;
+    if (!scores || !items || !out_ids || m < 0 || n_scores <= 0) return fail(h, IFR_ERR_ARG, "ifr_rank_items_f64: bad argument");
+    IFR_HIP(h, hipSetDevice(h->device));
+    int rc = ifr::launch_rank_items_f64(scores, n_scores, items, m, out_ids, &h->ws_sort, &h->ws_sort_bytes, (hipStream_t)stream);
+    if (rc) return fail(h, rc, "ifr_rank_items_f64: sort failed");
+    return IFR_OK;
+}
+
+int ifr_auc_dense_f64(ifr_handle h, const int32_t *user_ids, int64_t n, const double *scores, int64_t ld, double *out_auc, void *stream)
+{
+    if (!h) return IFR_ERR_ARG;
+    if (!h->tr_ptr || h->n_items <= 0) return fail(h, IFR_ERR_STATE, "ifr_auc_dense_f64: model / truth CSR not set");
+    if (n == 0) return IFR_OK;
+    const int64_t cat = catalogue_items(h);
+    if (!user_ids || !scores || !out_auc || n < 0 || ld < cat) return fail(h, IFR_ERR_ARG, "ifr_auc_dense_f64: bad argument");
+    if (h->tr_max_row > ifr::auc_max_pos_f64()) return fail(h, IFR_ERR_ARG, "ifr_auc_dense_f64: more than 4096 positives in one row");
+    IFR_HIP(h, hipSetDevice(h->device));
+    if (ifr::launch_auc_f64(scores, ld, user_ids, n, (int)cat, h->ex_ptr, h->ex_idx, h->ex_rows, h->tr_ptr, h->tr_idx, h->tr_rows,
+                            h->tr_max_row, out_auc, (hipStream_t)stream))
+        return fail(h, IFR_ERR_HIP, "ifr_auc_dense_f64: launch failed");
+    return IFR_OK;
+}
+
+int ifr_rank_full_f64(ifr_handle h, const int32_t *user_ids, int64_t n, const double *scores, int64_t ld, int32_t *out_ids,
+                      int32_t *n_cand, void *stream)
+{
+    if (!h) return IFR_ERR_ARG;
+    if (h->n_items <= 0) return fail(h, IFR_ERR_STATE, "ifr_rank_full_f64: no model set");
+    if (n == 0) return IFR_OK;
+    const int64_t cat = catalogue_items(h);
+    if (!user_ids || !scores || !out_ids || !n_cand || n < 0 || ld < cat) return fail(h, IFR_ERR_ARG, "ifr_rank_full_f64: bad argument");
+    if ((uint64_t)n * (uint64_t)cat > 0xffffffffull)
+        return fail(h, IFR_ERR_ARG, "ifr_rank_full_f64: more than 2^32 - 1 (user, item) pairs in one call, split the user list");
+    IFR_HIP(h, hipSetDevice(h->device));
+    int rc = ifr::launch_rank_full_f64(scores, ld, user_ids, n, (int)cat, h->ex_ptr, h->ex_idx, h->ex_rows, out_ids, n_cand,
+                                       &h->ws_sort, &h->ws_sort_bytes, (hipStream_t)stream);
+    if (rc) return fail(h, rc, "ifr_rank_full_f64: sort failed");
+    return IFR_OK;
+}
+
+int ifr_select_topk_f64(ifr_handle h, const int32_t *user_ids, int64_t n, const double *scores, int64_t ld, int K, int32_t *out_ids,
+                        float *out_scores, void *stream)
+{
+    if (!h) return IFR_ERR_ARG;
+    if (h->n_items <= 0) return fail(h, IFR_ERR_STATE, "ifr_select_topk_f64: no model set");
+    if (n == 0) return IFR_OK;
+    const int64_t cat = catalogue_items(h);
+    if (!user_ids || !scores || !out_ids || !out_scores || n < 0 || ld < cat) return fail(h, IFR_ERR_ARG, "ifr_select_topk_f64: bad argument");
+    if (K < 1 || K > ifr::select_topk_max_k()) return fail(h, IFR_ERR_ARG, "ifr_select_topk_f64: K must be in [1, 1024]");
+    IFR_HIP(h, hipSetDevice(h->device));
+    if (ifr::launch_select_topk_f64(scores, ld, user_ids, n, (int)cat, h->ex_ptr, h->ex_idx, h->ex_rows, K, out_ids, out_scores,
+                                    (hipStream_t)stream))
+        return fail(h, IFR_ERR_HIP, "ifr_select_topk_f64: launch failed (more than 2^24 rows in one call?)");
+    return IFR_OK;
+}
+
+int ifr_pad_scores_min_f64(ifr_handle h, double *scores, int64_t n, int64_t ld, void *stream)
+{
+    if (!h) return IFR_ERR_ARG;
+    if (h->n_items <= 0) return fail(h, IFR_ERR_STATE, "ifr_pad_scores_min_f64: no model set");
+    const int64_t cat = catalogue_items(h);
+    if (n == 0 || cat == h->n_items) return IFR_OK;
+    if (!scores || n < 0 || ld < cat) return fail(h, IFR_ERR_ARG, "ifr_pad_scores_min_f64: null argument or ld < catalogue_items");
+    IFR_HIP(h, hipSetDevice(h->device));
+    if (ifr::launch_pad_rows_min_f64(scores, n, ld, (int)h->n_items, (int)cat, (hipStream_t)stream))
+        return fail(h, IFR_ERR_HIP, "ifr_pad_scores_min_f64: launch failed");
+    return IFR_OK;
 }
 
 int ifr_rank_items(ifr_handle h, const float *scores, int64_t n_scores, const int32_t *items, int64_t m,

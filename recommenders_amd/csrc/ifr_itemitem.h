@@ -31,6 +31,7 @@ struct ItemItemParams {
     int64_t ex_rows;
     int K, KL;
     float *part_scores;          // [n][n_chunks][KL]   (TOPK)
+    double *part_scores64;       // ... of the fp64 option (then part_scores is null): the lists are ranked on the fp64 sums
     int32_t *part_ids;
     float *out;                  // [n][ld]             (dense rows)
     double *out64;               // [n][ld]             (dense rows of the fp64 option, instead of out)
@@ -38,6 +39,9 @@ struct ItemItemParams {
 };
 
 int launch_item_item(const ItemItemParams &p, bool sparse, bool topk, hipStream_t stream);
+// fp64 option: merge the per-chunk lists (double scores) of every user into the final top K, ranked on the doubles
+int launch_merge_topk_f64(const double *part_scores, const int32_t *part_ids, int64_t n, int n_lists, int KL, int K, int32_t *out_ids,
+                          float *out_scores, hipStream_t stream);
 int launch_item_sparse_topk(const ItemItemParams &p, int32_t *out_ids, float *out_scores, hipStream_t stream);
 int item_sparse_pass_capacity();
 int item_sparse_read_phases(unsigned long long *out16);   // dev build only (make ABLATE=1), else -1

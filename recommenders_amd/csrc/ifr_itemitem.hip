@@ -53,12 +53,13 @@ __global__ __launch_bounds__(II_BLOCK, 3) void item_item_kernel(ItemItemParams p
 {
     constexpr int CHUNK = PASSES * II_PASS;
     // sparse: int64 accumulators, later reused for the fp32 scores of the epilogue
-    __shared__ __attribute__((aligned(16))) unsigned char buf[SPARSE ? CHUNK * 8 : (TOPK ? CHUNK * 4 : 16)];
+    __shared__ __attribute__((aligned(16))) unsigned char buf[SPARSE ? CHUNK * 8 : (TOPK ? CHUNK * (F64 ? 8 : 4) : 16)];
     __shared__ uint32_t bm[TOPK ? CHUNK / 32 : 1];
     __shared__ int hj[II_HIST];
     __shared__ float hx[II_HIST];
     __shared__ int64_t sb[SPARSE ? II_HIST : 1], se[SPARSE ? II_HIST : 1];
     __shared__ float red_s[II_BLOCK / 64];
+    __shared__ double red_d[F64 && TOPK ? II_BLOCK / 64 : 1];
     __shared__ int red_i[II_BLOCK / 64];
     __shared__ int win_id;
     float *sc = reinterpret_cast<float *>(buf);
@@ -159,11 +160,91 @@ __global__ __launch_bounds__(II_BLOCK, 3) void item_item_kernel(ItemItemParams p
                     double s = a64[q][v];
                     if (p.pen != nullptr) s *= (double)p.pen[col];
                     if (!TOPK && p.out64 != nullptr && col < p.n_items) p.out64[i * p.ld + col] = s;
+                    a64[q][v] = s;
                     acc[q][v] = (float)s;
                 }
             }
         }
         if (!TOPK && p.out64 != nullptr) return;
+        if (TOPK) {
+            // ---- the epilogue below, on the fp64 sums themselves: the reference orders its float64 scores
+            // (recom_ease.py:123-124 -> recommender.py:643-652), so nothing is rounded before it is ranked
+            double *const sd = reinterpret_cast<double *>(buf);
+            for (int w = tid; w < CHUNK / 32; w += II_BLOCK) bm[w] = 0;
+            __syncthreads();
+            if (p.ex_ptr != nullptr && u >= 0 && u < p.ex_rows) {
+                const int64_t eb = p.ex_ptr[u], ee = p.ex_ptr[u + 1];
+                int64_t lo = eb, hi = ee;
+                while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (p.ex_idx[mid] < c0) lo = mid + 1; else hi = mid; }
+                for (int64_t e = lo + tid; e < ee; e += II_BLOCK) {
+                    const int it = p.ex_idx[e] - c0;
+                    if (it >= CHUNK) break;
+                    atomicOr(&bm[it >> 5], 1u << (it & 31));
+                }
+            }
+            __syncthreads();
+            const double dnan = __longlong_as_double(0x7ff8000000000000LL);
+            auto beats64 = [](double s, int id, double s2, int id2) { return (s > s2) || (s == s2 && id < id2); };
+            double lmax = -INFINITY;
+            int lid = II_NONE;
+#pragma unroll
+            for (int q = 0; q < PASSES; ++q) {
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int loc = q * II_PASS + 4 * tid + v;
+                    const int col = c0 + loc;
+                    double s = q < npass ? a64[q][v] + 0.0 : 0.0;                 // + 0: -0 ranks as +0
+                    const bool dead = col >= p.n_items || ((bm[loc >> 5] >> (loc & 31)) & 1u) || !(s == s);
+                    if (dead) s = dnan;
+                    sd[loc] = s;
+                    if (!dead && beats64(s, col, lmax, lid)) { lmax = s; lid = col; }
+                }
+            }
+            const int lane = tid & 63, wave = tid >> 6;
+            const int64_t obase = (i * p.n_chunks + chunk) * p.KL;
+            for (int r = 0; r < p.KL; ++r) {
+                double bs = lmax;
+                int bi = lid;
+#pragma unroll
+                for (int off = 32; off >= 1; off >>= 1) {
+                    const double os = __shfl_xor(bs, off);
+                    const int oi = __shfl_xor(bi, off);
+                    if (oi != II_NONE && (bi == II_NONE || beats64(os, oi, bs, bi))) { bs = os; bi = oi; }
+                }
+                if (lane == 0) { red_d[wave] = bs; red_i[wave] = bi; }
+                __syncthreads();
+                if (tid == 0) {
+                    double ws = red_d[0];
+                    int wi = red_i[0];
+                    for (int w = 1; w < II_BLOCK / 64; ++w)
+                        if (red_i[w] != II_NONE && (wi == II_NONE || beats64(red_d[w], red_i[w], ws, wi))) { ws = red_d[w]; wi = red_i[w]; }
+                    win_id = wi;
+                    p.part_scores64[obase + r] = wi == II_NONE ? -INFINITY : ws;
+                    p.part_ids[obase + r] = wi;
+                }
+                __syncthreads();
+                const int wi = win_id;
+                if (wi == II_NONE || r >= p.K - 1) {
+                    if (tid == 0)
+                        for (int rr = r + 1; rr < p.KL; ++rr) { p.part_scores64[obase + rr] = -INFINITY; p.part_ids[obase + rr] = II_NONE; }
+                    break;
+                }
+                if (wi == lid) {
+                    sd[wi - c0] = dnan;
+                    lmax = -INFINITY; lid = II_NONE;
+#pragma unroll
+                    for (int q = 0; q < PASSES; ++q) {
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) {
+                            const int loc = q * II_PASS + 4 * tid + v;
+                            const double s = sd[loc];
+                            if (s == s && beats64(s, c0 + loc, lmax, lid)) { lmax = s; lid = c0 + loc; }
+                        }
+                    }
+                }
+            }
+            return;
+        }
     } else {
         for (int64_t base = hb; base < he; base += II_HIST) {
             const int m = (int)min((int64_t)II_HIST, he - base);
@@ -868,6 +949,48 @@ int launch_item_sparse_topk(const ItemItemParams &p, int32_t *out_ids, float *ou
 }
 int item_sparse_pass_capacity() { return SP_CAP; }
 int item_sparse_max_chunks() { return SP_MAXCH; }
+
+// fp64 option: one wave per user ranks the n_lists * KL partial entries by counting (score descending on the DOUBLES,
+// item index ascending) and writes the first K; the scores leave as fp32 (rounded once, after the ranking).
+__global__ __launch_bounds__(64) void merge_topk64_kernel(const double *part_scores, const int32_t *part_ids, int n_lists, int KL, int K,
+                                                          int32_t *out_ids, float *out_scores)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char m64_lds[];
+    const int E = n_lists * KL;
+    double *const es = reinterpret_cast<double *>(m64_lds);
+    int *const ei = reinterpret_cast<int *>(es + E);
+    const int64_t u = blockIdx.x;
+    const int lane = threadIdx.x;
+    for (int e = lane; e < E; e += 64) { es[e] = part_scores[u * E + e]; ei[e] = part_ids[u * E + e]; }
+    __syncthreads();
+    int n_valid = 0;
+    for (int e = lane; e < E; e += 64) {
+        const int id = ei[e];
+        if (id == II_NONE) continue;
+        const double s = es[e];
+        ++n_valid;
+        int rank = 0;
+        for (int x = 0; x < E; ++x) {
+            const int id2 = ei[x];
+            const double s2 = es[x];
+            rank += (id2 != II_NONE && ((s2 > s) || (s2 == s && id2 < id))) ? 1 : 0;
+        }
+        if (rank < K) { out_ids[u * K + rank] = id; out_scores[u * K + rank] = (float)s; }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) n_valid += __shfl_xor(n_valid, off);
+    for (int r = n_valid + lane; r < K; r += 64) { out_ids[u * K + r] = -1; out_scores[u * K + r] = -INFINITY; }
+}
+
+int launch_merge_topk_f64(const double *part_scores, const int32_t *part_ids, int64_t n, int n_lists, int KL, int K, int32_t *out_ids,
+                          float *out_scores, hipStream_t stream)
+{
+    const size_t smem = (size_t)n_lists * KL * 12;
+    if (n <= 0 || smem > 60000) return -1;
+    hipLaunchKernelGGL(merge_topk64_kernel, dim3((unsigned)n), dim3(64), smem, stream, part_scores, part_ids, n_lists, KL, K, out_ids,
+                       out_scores);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
 
 int launch_item_item(const ItemItemParams &p, bool sparse, bool topk, hipStream_t stream)
 {

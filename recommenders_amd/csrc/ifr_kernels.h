@@ -1188,9 +1188,10 @@ __global__ __launch_bounds__(BLOCK) void metrics_list_kernel(ListMetricParams p)
 // O(I log P) instead of the O(I log I) sort + O(I log P) sweep; one read of the row.
 // ------------------------------------------------------------------------------------
 constexpr int DM_MAX_POS = 4096;
+constexpr int DM_MAX_POS_F64 = 2048;     // fp64 rows: 128-bit (score key, item) keys, 20 bytes of LDS per positive
 
 struct DenseMetricParams {
-    const float *scores;         // [n][ld]
+    const void *scores;          // [n][ld] fp32, or fp64 for metrics_dense_kernel<double>
     int64_t ld;
     const int32_t *user_ids;
     int n_items;                 // columns ranked (catalogue)
@@ -1214,12 +1215,41 @@ __device__ __forceinline__ unsigned long long rank_key(float s, int item)
     return ((unsigned long long)(~b) << 32) | (uint32_t)item;   // smaller key = earlier in the ranking
 }
 
+// (score key, item) as ONE orderable integer, smaller = earlier in the ranking: 64 bits for fp32 rows, 128 bits for
+// fp64 rows (the 64-bit image of the double, then the item), so that fp64 scores are ranked unrounded
+template <typename S> struct RankKeyOf;
+template <> struct RankKeyOf<float> {
+    typedef unsigned long long T;
+    static __device__ __forceinline__ T make(float s, int item) { return rank_key(s, item); }
+};
+template <> struct RankKeyOf<double> {
+    typedef unsigned __int128 T;
+    static __device__ __forceinline__ T make(double s, int item)
+    {
+        unsigned long long b = (unsigned long long)__double_as_longlong(s + 0.0);       // + 0: -0 ranks as +0
+        b = (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+        return ((T)(~b) << 32) | (T)(uint32_t)item;
+    }
+};
+__device__ __forceinline__ void dm_load4(const float *p, float (&v)[4])
+{
+    const float4 s = *reinterpret_cast<const float4 *>(p);
+    v[0] = s.x; v[1] = s.y; v[2] = s.z; v[3] = s.w;
+}
+__device__ __forceinline__ void dm_load4(const double *p, double (&v)[4])
+{
+    const double2 a = *reinterpret_cast<const double2 *>(p), b = *reinterpret_cast<const double2 *>(p + 2);
+    v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y;
+}
+
+template <typename S>
 __global__ __launch_bounds__(BLOCK) void metrics_dense_kernel(DenseMetricParams p)
 {
+    typedef typename RankKeyOf<S>::T KT;
     // sized by the launch for the longest truth row of the handle (p.cap = power of two >= that): short rows
     // leave room for more resident workgroups
     extern __shared__ __attribute__((aligned(16))) unsigned char dm_lds[];
-    unsigned long long *const kp = reinterpret_cast<unsigned long long *>(dm_lds);          // [p.cap]
+    KT *const kp = reinterpret_cast<KT *>(dm_lds);                                           // [p.cap]
     uint32_t *const cnt = reinterpret_cast<uint32_t *>(kp + p.cap);                          // [p.cap + 1]
     __shared__ double red[BLOCK / 64][2 * MAX_KS + 1];
     __shared__ int red_i[BLOCK / 64][MAX_KS + 2];
@@ -1229,7 +1259,7 @@ __global__ __launch_bounds__(BLOCK) void metrics_dense_kernel(DenseMetricParams 
     const int64_t i = blockIdx.x;
     const int ncol = NM * p.n_k + 2;
     const int u = p.user_ids[i];
-    const float *row = p.scores + i * p.ld;
+    const S *row = reinterpret_cast<const S *>(p.scores) + i * p.ld;
     int64_t b = 0, e = 0, eb = 0, ee = 0;
     if (u >= 0 && u < p.tr_rows) { b = p.tr_ptr[u]; e = p.tr_ptr[u + 1]; }
     if (p.ex_ptr != nullptr && u >= 0 && u < p.ex_rows) { eb = p.ex_ptr[u]; ee = p.ex_ptr[u + 1]; }
@@ -1248,10 +1278,10 @@ __global__ __launch_bounds__(BLOCK) void metrics_dense_kernel(DenseMetricParams 
     {
         int v = 0;
         for (int q = tid; q < np2; q += BLOCK) {
-            unsigned long long k = ~0ull;
+            KT k = ~(KT)0;
             if (q < n_pos) {
                 const int it = p.tr_idx[b + q];
-                if (it >= 0 && it < p.n_items && !in_sorted_row(p.ex_idx, eb, ee, it)) { k = rank_key(row[it], it); ++v; }
+                if (it >= 0 && it < p.n_items && !in_sorted_row(p.ex_idx, eb, ee, it)) { k = RankKeyOf<S>::make(row[it], it); ++v; }
             }
             kp[q] = k;
         }
@@ -1263,7 +1293,7 @@ __global__ __launch_bounds__(BLOCK) void metrics_dense_kernel(DenseMetricParams 
             for (int q = tid; q < np2; q += BLOCK) {
                 const int x = q ^ j;
                 if (x > q) {
-                    const unsigned long long a = kp[q], c = kp[x];
+                    const KT a = kp[q], c = kp[x];
                     const bool up = (q & kk) == 0;
                     if ((a > c) == up) { kp[q] = c; kp[x] = a; }
                 }
@@ -1275,7 +1305,7 @@ __global__ __launch_bounds__(BLOCK) void metrics_dense_kernel(DenseMetricParams 
     for (int q = tid; q <= P; q += BLOCK) cnt[q] = 0u;
     __syncthreads();
     // positives that beat `key`: branch-free lower bound over the padded array (pads beat nothing)
-    auto beaten_from = [&](unsigned long long key) -> int {
+    auto beaten_from = [&](KT key) -> int {
         int c = 0;
         for (int step = np2 >> 1; step >= 1; step >>= 1) c += kp[c + step - 1] < key ? step : 0;
         c += kp[c] < key ? 1 : 0;
@@ -1286,18 +1316,19 @@ __global__ __launch_bounds__(BLOCK) void metrics_dense_kernel(DenseMetricParams 
     if ((p.ld & 3) == 0 && (reinterpret_cast<uintptr_t>(p.scores) & 15) == 0) {
         const int n4 = p.n_items & ~3;
         for (int it = 4 * tid; it < n4; it += 4 * BLOCK) {
-            const float4 s = *reinterpret_cast<const float4 *>(row + it);
-            const unsigned long long k0 = rank_key(s.x, it), k1 = rank_key(s.y, it + 1), k2 = rank_key(s.z, it + 2),
-                                     k3 = rank_key(s.w, it + 3);
+            S sv[4];
+            dm_load4(row + it, sv);
+            const KT k0 = RankKeyOf<S>::make(sv[0], it), k1 = RankKeyOf<S>::make(sv[1], it + 1), k2 = RankKeyOf<S>::make(sv[2], it + 2),
+                     k3 = RankKeyOf<S>::make(sv[3], it + 3);
             int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
             for (int step = np2 >> 1; step >= 1; step >>= 1) {
-                const unsigned long long a0 = kp[c0 + step - 1], a1 = kp[c1 + step - 1], a2 = kp[c2 + step - 1], a3 = kp[c3 + step - 1];
+                const KT a0 = kp[c0 + step - 1], a1 = kp[c1 + step - 1], a2 = kp[c2 + step - 1], a3 = kp[c3 + step - 1];
                 c0 += a0 < k0 ? step : 0;
                 c1 += a1 < k1 ? step : 0;
                 c2 += a2 < k2 ? step : 0;
                 c3 += a3 < k3 ? step : 0;
             }
-            const unsigned long long a0 = kp[c0], a1 = kp[c1], a2 = kp[c2], a3 = kp[c3];
+            const KT a0 = kp[c0], a1 = kp[c1], a2 = kp[c2], a3 = kp[c3];
             c0 += a0 < k0 ? 1 : 0;
             c1 += a1 < k1 ? 1 : 0;
             c2 += a2 < k2 ? 1 : 0;
@@ -1309,12 +1340,12 @@ __global__ __launch_bounds__(BLOCK) void metrics_dense_kernel(DenseMetricParams 
         }
         it0 = n4;
     }
-    for (int it = it0 + tid; it < p.n_items; it += BLOCK) atomicAdd(&cnt[beaten_from(rank_key(row[it], it))], 1u);
+    for (int it = it0 + tid; it < p.n_items; it += BLOCK) atomicAdd(&cnt[beaten_from(RankKeyOf<S>::make(row[it], it))], 1u);
     {
         int c = 0;
         for (int64_t q = eb + tid; q < ee; q += BLOCK) {
             const int it = p.ex_idx[q];
-            if (it >= 0 && it < p.n_items) { atomicSub(&cnt[beaten_from(rank_key(row[it], it))], 1u); ++c; }
+            if (it >= 0 && it < p.n_items) { atomicSub(&cnt[beaten_from(RankKeyOf<S>::make(row[it], it))], 1u); ++c; }
         }
         if (c) atomicAdd(&s_nex, c);
     }

@@ -287,7 +287,7 @@ class HipScorer:
         buf = None
         for b in range(0, n, step):
             ub = u[b:b + step]
-            dense = self.score_dense(ub, None if buf is None else buf[: ub.numel()])
+            dense = self.score_rows(ub, None if buf is None else buf[: ub.numel()])
             buf = dense if buf is None else buf
             self.select_topk(ub, dense, K, out_ids[b:b + step], out_scores[b:b + step])
         return out_ids, out_scores
@@ -366,8 +366,9 @@ class HipScorer:
             out_scores = torch.empty((n, K), dtype=torch.float32, device=self.device)
         if not (out_ids.is_contiguous() and out_scores.is_contiguous()):
             raise ValueError("select_topk: output tensors must be contiguous")
-        self._check(self._lib.ifr_select_topk(self._h, u.data_ptr(), n, scores.data_ptr(), scores.stride(0), int(K),
-                                              out_ids.data_ptr(), out_scores.data_ptr(), self._stream()))
+        fn = self._lib.ifr_select_topk_f64 if scores.dtype == torch.float64 else self._lib.ifr_select_topk
+        self._check(fn(self._h, u.data_ptr(), n, scores.data_ptr(), scores.stride(0), int(K),
+                       out_ids.data_ptr(), out_scores.data_ptr(), self._stream()))
         return out_ids, out_scores
 
     def eval_topk_metrics(self, user_ids, topk_ids, ks):
@@ -413,9 +414,9 @@ class HipScorer:
         per_user = torch.empty((n, ncol), dtype=torch.float64, device=self.device)
         evaluated = torch.empty((n,), dtype=torch.int32, device=self.device)
         sums = torch.empty((ncol + 1,), dtype=torch.float64, device=self.device)
-        self._check(self._lib.ifr_eval_dense_metrics(
-            self._h, u.data_ptr(), n, scores.data_ptr(), scores.stride(0), ks_arr, len(ks),
-            per_user.data_ptr(), evaluated.data_ptr(), sums.data_ptr(), self._stream()))
+        fn = self._lib.ifr_eval_dense_metrics_f64 if scores.dtype == torch.float64 else self._lib.ifr_eval_dense_metrics
+        self._check(fn(self._h, u.data_ptr(), n, scores.data_ptr(), scores.stride(0), ks_arr, len(ks),
+                       per_user.data_ptr(), evaluated.data_ptr(), sums.data_ptr(), self._stream()))
         return per_user, evaluated, sums
 
     def rank_items(self, scores_row, items):
@@ -423,8 +424,9 @@ class HipScorer:
         torch = _torch()
         it = self._dev_i32(items)
         out = torch.empty_like(it)
-        self._check(self._lib.ifr_rank_items(self._h, scores_row.data_ptr(), scores_row.numel(), it.data_ptr(),
-                                             it.numel(), out.data_ptr(), self._stream()))
+        fn = self._lib.ifr_rank_items_f64 if scores_row.dtype == torch.float64 else self._lib.ifr_rank_items
+        self._check(fn(self._h, scores_row.data_ptr(), scores_row.numel(), it.data_ptr(), it.numel(), out.data_ptr(),
+                       self._stream()))
         return out
 
     def set_catalogue_items(self, n_total):
@@ -434,11 +436,44 @@ class HipScorer:
         self._check(self._lib.ifr_set_option(self._h, b"catalogue_items", 0 if n_total == self.n_items else n_total))
         self.catalogue_items = max(n_total, self.n_items)
 
+    def rows_are_f64(self):
+        """True for an item matrix installed with precision="f64": its native score rows are float64, and everything
+        that ranks them orders the float64 values (the reference's precision for EASE, recom_ease.py:123-124)."""
+        return self.item_model == "dense" and getattr(self, "item_precision", "f32") == "f64"
+
+    def max_dense_metric_pos(self):
+        """Positives per row ifr_eval_dense_metrics[_f64] takes (float64 rows: 128-bit keys, half as many fit the LDS)."""
+        return 2048 if self.rows_are_f64() else MAX_DENSE_METRIC_POS
+
+    def row_bytes_per_item(self):
+        return 8 if self.rows_are_f64() else 4
+
     def new_score_rows(self, n_rows):
-        """An uninitialised [n_rows, catalogue] fp32 buffer for score_dense(out=...): callers that loop over batches
-        allocate it once (two live buffers would double the footprint the batch size was chosen for)."""
+        """An uninitialised [n_rows, catalogue] buffer for score_rows(out=...) in the model's native score type (fp32;
+        float64 for precision="f64"): callers that loop over batches allocate it once (two live buffers would double
+        the footprint the batch size was chosen for)."""
+        torch = _torch()
         cols = max(getattr(self, "catalogue_items", 0), self.n_items)
-        return _torch().empty((int(n_rows), cols), dtype=_torch().float32, device=self.device)
+        cols = (cols + 3) // 4 * 4                         # 16-byte aligned rows: the consumers read 4 scores at a time
+        return torch.empty((int(n_rows), cols), dtype=torch.float64 if self.rows_are_f64() else torch.float32,
+                           device=self.device)
+
+    def score_rows(self, user_ids, out=None):
+        """Score rows [n, catalogue] in the model's native score type: score_dense (fp32), or for precision="f64"
+        the float64 sums (ifr_score_dense_f64), padded with the row minimum for unknown catalogue items.  auc_dense,
+        eval_dense_metrics, rank_full, select_topk and rank_items take either and rank what they are given."""
+        if not self.rows_are_f64():
+            return self.score_dense(user_ids, out)
+        torch = _torch()
+        u = self._dev_users(user_ids)
+        n = u.numel()
+        cols = max(getattr(self, "catalogue_items", 0), self.n_items)
+        if out is None:
+            out = torch.empty((n, (cols + 3) // 4 * 4), dtype=torch.float64, device=self.device)
+        self._check(self._lib.ifr_score_dense_f64(self._h, u.data_ptr(), n, out.data_ptr(), out.stride(0), self._stream()))
+        if cols > self.n_items:
+            self._check(self._lib.ifr_pad_scores_min_f64(self._h, out.data_ptr(), n, out.stride(0), self._stream()))
+        return out[:n, :cols]
 
     def score_dense(self, user_ids, out=None):
         """Score rows [n, catalogue] (catalogue = n_items unless set_catalogue_items widened it)."""
@@ -464,11 +499,12 @@ class HipScorer:
         return out
 
     def auc_dense(self, user_ids, scores):
+        """AUC per user from dense score rows (fp32, or float64 rows of a precision="f64" model)."""
         torch = _torch()
         u = self._dev_i32(user_ids)
         out = torch.empty((u.numel(),), dtype=torch.float64, device=self.device)
-        self._check(self._lib.ifr_auc_dense(self._h, u.data_ptr(), u.numel(), scores.data_ptr(), scores.stride(0),
-                                            out.data_ptr(), self._stream()))
+        fn = self._lib.ifr_auc_dense_f64 if scores.dtype == torch.float64 else self._lib.ifr_auc_dense
+        self._check(fn(self._h, u.data_ptr(), u.numel(), scores.data_ptr(), scores.stride(0), out.data_ptr(), self._stream()))
         return out
 
     def rank_full(self, user_ids, scores):
@@ -478,8 +514,9 @@ class HipScorer:
         n = u.numel()
         ids = torch.empty((n, scores.stride(0)), dtype=torch.int32, device=self.device)
         n_cand = torch.empty((n,), dtype=torch.int32, device=self.device)
-        self._check(self._lib.ifr_rank_full(self._h, u.data_ptr(), n, scores.data_ptr(), scores.stride(0),
-                                            ids.data_ptr(), n_cand.data_ptr(), self._stream()))
+        fn = self._lib.ifr_rank_full_f64 if scores.dtype == torch.float64 else self._lib.ifr_rank_full
+        self._check(fn(self._h, u.data_ptr(), n, scores.data_ptr(), scores.stride(0), ids.data_ptr(), n_cand.data_ptr(),
+                       self._stream()))
         return ids, n_cand
 
     # ------------------------------------------------------------------ introspection

@@ -292,7 +292,9 @@ class _CacheOwner:
             eng.exclusion_source = excl
         eng.set_catalogue_items(self.n_items)
         rows = torch.as_tensor(np.asarray(block, np.int32), device=eng.device)
-        dense = eng.score_dense(rows)                                        # [b, n_items]
+        # [b, n_items] in the model's native score type: fp32, or the float64 sums of a precision="f64" model (ranked
+        # and handed out unrounded, like the one-user path through model.rank)
+        dense = eng.score_rows(rows) if hasattr(eng, "score_rows") else eng.score_dense(rows)
         ranked, n_cand = eng.rank_full(rows, dense)
         # candidates in ascending item index and the scores aligned with them (recommender.py:643): compaction of
         # the not-excluded columns, row by row
@@ -311,22 +313,34 @@ class _CacheOwner:
             src = np.arange(total) - np.repeat(first, lens) + np.repeat(starts, lens)
             c_idx = self.excl.indices[src].astype(np.int64)
             keep[torch.as_tensor(r_idx, device=eng.device), torch.as_tensor(c_idx, device=eng.device)] = False
-        def to_host(t):
-            # page-locked destination: three copies of ~100 KB per user are what this path costs, pageable memory
-            # moves them at a fifth of the link rate; the arrays handed out below are views of these buffers
-            h = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+        def to_host(t, slot):
+            # through ONE page-locked staging buffer per owner and slot (pageable memory moves these ~100 KB-per-user
+            # copies at a fifth of the link rate), then out into ordinary arrays: the cache entries must not keep
+            # page-locked memory alive -- walking every user would pin tens of GB of host RAM
+            t = t.contiguous()
+            need = t.numel() * t.element_size()
+            stage = self._staging.get(slot)
+            if stage is None or stage.numel() < need:
+                stage = torch.empty((max(need, 1 << 20),), dtype=torch.uint8, pin_memory=True)
+                self._staging[slot] = stage
+            h = stage[:need].view(t.dtype).view(t.shape)
             h.copy_(t, non_blocking=True)
             return h
-        cand_t = to_host(keep.nonzero()[:, 1])                               # int64, row-major: per user ascending
+        if not hasattr(self, "_staging"):
+            self._staging = {}
         sdt = getattr(m, "score_dtype", np.float32)
-        scores_t = to_host(dense[keep] if sdt == np.float32 else dense[keep].to(torch.float64))
-        ranked_t = to_host(ranked.to(torch.int64))
+        picked = dense[keep]
+        if (sdt == np.float64) != (picked.dtype == torch.float64):
+            picked = picked.to(torch.float64 if sdt == np.float64 else torch.float32)
+        cand_t = to_host(keep.nonzero()[:, 1], 0)                            # int64, row-major: per user ascending
+        scores_t = to_host(picked, 1)
+        ranked_t = to_host(ranked.to(torch.int64), 2)
         n_h = n_cand.cpu().numpy().astype(np.int64)
         torch.cuda.synchronize(eng.device)
-        cand_h, scores_h, ranked_h = cand_t.numpy(), scores_t.numpy(), ranked_t.numpy()
+        cand_h, scores_h, ranked_h = cand_t.numpy().copy(), scores_t.numpy().copy(), ranked_t.numpy()
         off = np.concatenate([[0], np.cumsum(n_h)])
         for i, v in enumerate(block):
-            caches[0][v] = ranked_h[i, : n_h[i]]
+            caches[0][v] = ranked_h[i, : n_h[i]].copy()
             caches[1][v] = scores_h[off[i]: off[i + 1]]
             caches[2][v] = cand_h[off[i]: off[i + 1]]
         return caches[0]._explicit[u], caches[1]._explicit[u]
@@ -589,14 +603,15 @@ def ranking_eval(model, metrics, train_set, test_set, val_set=None, rating_thres
         if need_list or need_auc:
             lst_ks = ks if ks else [-1]
             max_pos = int(np.diff(truth.indptr).max()) if truth.shape[0] else 0
-            dense_metrics = max_pos <= MAX_DENSE_METRIC_POS
+            dense_metrics = max_pos <= (eng.max_dense_metric_pos() if hasattr(eng, "max_dense_metric_pos") else MAX_DENSE_METRIC_POS)
             # rows only (counting metrics, AUC): 16 GB batches, large launches run 20 % faster per user than 1 GB
             # ones; the sorted-list fallback also holds 64-bit sort keys and ids per pair, so it keeps 2^28 pairs
             sorted_lists = need_list and not dense_metrics
             default_pairs = 1 << 28 if sorted_lists else 1 << 32
             # per row and item: 4 B of scores; the sorted-list branch adds 4 B of ranked ids, 16 B of sort keys (in and
             # out) and rocPRIM's temporary storage (below 4 B per item)
-            row_bytes = (4 + (24 if sorted_lists else 0)) * n_items
+            bpi = eng.row_bytes_per_item() if hasattr(eng, "row_bytes_per_item") else 4     # 8: float64 rows (precision="f64")
+            row_bytes = (bpi + ((20 + 2 * bpi) if sorted_lists else 0)) * n_items
             step = _rows_that_fit(eng, min(n, (batch_pairs or default_pairs) // max(1, n_items)), row_bytes)
             if sorted_lists:
                 step = max(1, min(step, (2 ** 32 - 1) // max(1, n_items)))        # ifr_rank_full: 32-bit pair count
@@ -605,7 +620,8 @@ def ranking_eval(model, metrics, train_set, test_set, val_set=None, rating_thres
             rows = eng.new_score_rows(step) if hasattr(eng, "new_score_rows") else None     # ONE buffer for every batch
             for b in range(0, n, step):
                 bu = dev_users[b:b + step]
-                dense = eng.score_dense(bu) if rows is None else eng.score_dense(bu, rows[: len(bu)])
+                score_rows = eng.score_rows if hasattr(eng, "score_rows") else eng.score_dense      # native score type
+                dense = score_rows(bu) if rows is None else score_rows(bu, rows[: len(bu)])
                 if need_auc:
                     auc[b:b + step] = eng.auc_dense(bu, dense).cpu().numpy()
                 if need_list and dense_metrics:

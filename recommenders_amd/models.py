@@ -270,16 +270,17 @@ class HipScoringMixin:
             item_scores = all_scores[cand]
             ranked = np.sort(cand, kind="stable")
         else:
-            exact = self._hip_score_row(eng, row)            # device [num_items]: fp32, or fp64 (precision="f64")
+            exact = self._hip_score_row(eng, row).contiguous()   # device [num_items]: fp32, or fp64 (precision="f64")
             if exact.numel() != total_items:
                 # unknown items get the minimum known score (recommender.py:631-635)
                 pad = torch.full((total_items - exact.numel(),), exact.min().item(), dtype=exact.dtype,
                                  device=exact.device)
                 exact = torch.cat([exact, pad])
-            known = exact.float()                            # ranking keys: the sum rounded once to fp32
+            # ranking keys: the scores themselves -- float64 sums are ordered as float64 (ifr_rank_items_f64), like the
+            # reference's argsort of its float64 scores (recommender.py:643-652)
             cand = np.arange(self.num_items) if item_indices is None else np.asarray(item_indices)
-            cand_dev = torch.as_tensor(cand.astype(np.int32), device=known.device)
-            ranked = eng.rank_items(known, cand_dev).cpu().numpy().astype(cand.dtype if cand.dtype.kind == "i" else np.int64)
+            cand_dev = torch.as_tensor(cand.astype(np.int32), device=exact.device)
+            ranked = eng.rank_items(exact, cand_dev).cpu().numpy().astype(cand.dtype if cand.dtype.kind == "i" else np.int64)
             item_scores = exact[cand_dev.long()].cpu().numpy().astype(self.score_dtype, copy=False)
         if k != -1 and k > len(cand):
             raise ValueError("kth(=%d) out of bounds (%d)" % (k, len(cand)))    # np.argpartition's error
@@ -450,7 +451,7 @@ class ItemItemScoringMixin(HipScoringMixin):
 
     def _hip_score_row(self, eng, row):
         if getattr(self, "precision", "f32") == "f64" and eng.item_model == "dense":
-            return eng.score_dense_f64(np.asarray([row], np.int32))[0]
+            return eng.score_dense_f64(np.asarray([row], np.int32))[0][: eng.n_items]
         return eng.score_dense(np.asarray([row], np.int32))[0]
 
 
@@ -524,10 +525,15 @@ class RP3_Beta(ItemItemScoringMixin, RecommenderBase):
     no host build in this package (the SciPy restatement is test infrastructure, the checker of the tests)."""
 
     def __init__(self, beta=0.7, name="RP3_beta", trainable=True, verbose=False, item_matrix="auto", init_params=None,
-                 **kwargs):
+                 precision="f32", **kwargs):
         RecommenderBase.__init__(self, name=name, trainable=trainable, verbose=verbose)
         self.beta = beta
         self.item_matrix = item_matrix
+        if precision not in ("f32", "f64"):
+            raise ValueError("precision must be 'f32' or 'f64'")
+        if precision == "f64" and (item_matrix != "dense" or not init_params):
+            raise ValueError("RP3_Beta(precision='f64') needs item_matrix='dense' and init_params (a float64 W)")
+        self.precision = precision
         ip = init_params or {}
         self.P_ui, self.W, self.item_degrees = ip.get("P_ui"), ip.get("W"), ip.get("item_degrees")
         if (self.W is None) != (self.P_ui is None) or (self.W is None) != (self.item_degrees is None):
@@ -569,6 +575,15 @@ class RP3_Beta(ItemItemScoringMixin, RecommenderBase):
         mode = self.item_matrix
         if mode == "auto":
             mode = "dense" if self.W.shape[0] <= 8192 else "csr"
+        if self.precision == "f64":
+            # float64 route: W stays float64 and carries 1/deg^beta (folded in float64: one rounding of 1e-16 per entry),
+            # every sum is a float64 chain and the float64 sums are what is ranked.  The history weights 1/deg(u) stay
+            # fp32: one common factor per user, which moves no order.  (The reference itself rounds P, P^2 and P^3 to
+            # fp32, graph_recommender.py:36-38, 83-84: its own values carry ~1e-7 of relative rounding.)
+            with np.errstate(divide="ignore", invalid="ignore"):
+                pen64 = 1.0 / (np.asarray(self.item_degrees).astype(np.float64) ** self.beta)
+                M = np.asarray(self.W.astype(np.float64).toarray()) * pen64[None, :]
+            return M, self.P_ui.astype(np.float32), None
         M = self.W.astype(np.float32)
         if mode == "dense":
             M = M.toarray()
