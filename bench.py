@@ -33,7 +33,6 @@ sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 PEAK_HBM_GBS = 8000.0            # same guide: HBM3E ~8 TB/s
-TOPK = 10
 
 # rocprofv3 --pmc passes of `python bench.py --config X` committed under profiles/ (tools/prof.sh): HBM bytes per launch
 # of the dominant kernel.  A constant from that file, not a measurement of the run that prints it: `traffic_source`.
@@ -69,7 +68,7 @@ def host_description(threads):
             "threads_source": "scheduler affinity capped by OMP_NUM_THREADS (the box's CPU share for one GPU)"}
 
 
-def cpu_baseline(w, n_sample, chain):
+def cpu_baseline(w, n_sample, chain, topk, want_auc=False):
     """The oracle's C port of the per-user reference loop (oracle/ifr_oracle.c), timed on this
     box's host cores over a bounded user sample of the same workload."""
     from oracle import oracle as orc
@@ -79,7 +78,7 @@ def cpu_baseline(w, n_sample, chain):
     t = time.perf_counter()
     ids, sc, met, ev = orc.c_ranking_eval_factor(
         w["U"], w["V"], w["ibase"], w["ubase"], users, w["excl_ptr"], w["excl_idx"], w["truth_ptr"], w["truth_idx"],
-        [TOPK], False, TOPK, kperm=kp, n_threads=threads)
+        [topk], want_auc, topk, kperm=kp, n_threads=threads)
     dt = time.perf_counter() - t
     out = dict(value=n_sample / dt, unit="users/s", kind="port",
                sample=f"{n_sample} users x {w['n_items']} items of the same workload, "
@@ -88,7 +87,7 @@ def cpu_baseline(w, n_sample, chain):
     return out, ids, met, ev
 
 
-def cpu_baseline_item(w, n_sample, shift):
+def cpu_baseline_item(w, n_sample, shift, topk):
     """The same per-user loop for an item-item model (oracle/ifr_oracle.c orc_ranking_eval_item)."""
     from oracle import oracle as orc
     threads = host_threads()
@@ -100,13 +99,38 @@ def cpu_baseline_item(w, n_sample, shift):
     t = time.perf_counter()
     ids, sc, met, ev = orc.c_ranking_eval_item(M, m_csr, shift, w["n_items"], w["col_scale"], w["h_ptr"], w["h_idx"],
                                                w["h_val"], users, w["excl_ptr"], w["excl_idx"], w["truth_ptr"],
-                                               w["truth_idx"], [TOPK], False, TOPK, n_threads=threads)
+                                               w["truth_idx"], [topk], False, topk, n_threads=threads)
     dt = time.perf_counter() - t
     out = dict(value=n_sample / dt, unit="users/s", kind="port",
                sample=f"{n_sample} users x {w['n_items']} items of the same workload, "
                       f"oracle/ifr_oracle.c orc_ranking_eval_item, {dt:.1f} s")
     out.update(host_description(threads))
     return out, ids, met, ev
+
+
+def cpu_baseline_item_f64(w, n_sample, topk):
+    """The float64 option of the dense item matrix on the CPU: the oracle's fp64 fma chain per user
+    (orc_score_item_dense_f64) and the canonical ranking of the float64 sums."""
+    from oracle import oracle as orc
+    # only the rows of M the sampled users' histories read (float64 copies of all 50 K rows would be 20 GB of host memory)
+    e_end = int(w["h_ptr"][n_sample])
+    rows, h_local = np.unique(w["h_idx"][:e_end], return_inverse=True)
+    M = w["M"]
+    M = (M[rows] if isinstance(M, np.ndarray) else M[rows.astype(np.int64)].cpu().numpy()).astype(np.float64)
+    ids = np.full((n_sample, topk), -1, np.int32)
+    t = time.perf_counter()
+    for u in range(n_sample):
+        a, b = w["h_ptr"][u], w["h_ptr"][u + 1]
+        s64, _ = orc.c_score_item_dense_f64(M, h_local[a:b], w["h_val"][a:b], w["col_scale"])
+        cand = np.setdiff1d(np.arange(w["n_items"]), w["excl_idx"][w["excl_ptr"][u]: w["excl_ptr"][u + 1]])
+        head = orc.canonical_rank(cand, s64[cand], topk)
+        ids[u, : len(head)] = head
+    dt = time.perf_counter() - t
+    out = dict(value=n_sample / dt, unit="users/s", kind="port",
+               sample=f"{n_sample} users x {w['n_items']} items of the same workload, float64 matrix, "
+                      f"oracle orc_score_item_dense_f64 + canonical ranking of the float64 sums, 1 thread, {dt:.1f} s")
+    out.update(host_description(1))
+    return out, ids
 
 
 def item_algorithmic_bytes(w):
@@ -119,7 +143,7 @@ def item_algorithmic_bytes(w):
     return 8.0 * float(row_nnz[w["h_idx"][: w["h_ptr"][n]]].sum())
 
 
-def cpu_strong(w, n_sample):
+def cpu_strong(w, n_sample, topk=10):
     """Informational: batched sgemm + argpartition on all host threads."""
     t = time.perf_counter()
     done = 0
@@ -128,7 +152,7 @@ def cpu_strong(w, n_sample):
         S = w["U"][us] @ w["V"].T
         for r, u in enumerate(us):
             S[r, w["excl_idx"][w["excl_ptr"][u]: w["excl_ptr"][u + 1]]] = -np.inf
-        part = np.argpartition(-S, TOPK, axis=1)[:, :TOPK]
+        part = np.argpartition(-S, topk, axis=1)[:, :topk]
         np.take_along_axis(S, part, 1).argsort(1)
         done += len(us)
     dt = time.perf_counter() - t
@@ -173,7 +197,10 @@ class Dist:
             torch.cuda.synchronize(self.dev)
 
 
-def build_workload(config, args, rank, dev):
+_HOST_WORKLOADS = {}      # (config, k, rank): NumPy workloads are reused by the variants of one configuration
+
+
+def build_workload(config, args, rank, dev, var):
     """(engine with model + CSRs resident, workload dict with the HOST arrays the CPU baseline samples)."""
     from recommenders_amd import HipScorer, synth
     sc = HipScorer(dev.index)
@@ -182,11 +209,15 @@ def build_workload(config, args, rank, dev):
             name, value = opt.split("=")
             sc.set_option(name, int(value))
     if config in synth.ITEM_CONFIGS:
-        w = synth.make_item(config, n_users=args.users, n_items=args.items,
-                            seed=synth.ITEM_CONFIGS[config][3] + 1000 * rank, device=dev)
+        key = (config, None, rank)
+        if key not in _HOST_WORKLOADS:
+            _HOST_WORKLOADS.clear()
+            _HOST_WORKLOADS[key] = synth.make_item(config, n_users=args.users, n_items=args.items,
+                                                   seed=synth.ITEM_CONFIGS[config][3] + 1000 * rank, device=dev)
+        w = _HOST_WORKLOADS[key]
         if w["M"] is not None:
-            # --item-f64 (variant, not the headline arithmetic): the float64 option of the dense item matrix
-            sc.set_item_matrix_dense(w["M"], w["col_scale"], precision="f64" if args.item_f64 else "f32")
+            # item_f64 (variant, not the headline arithmetic): the float64 option of the dense item matrix
+            sc.set_item_matrix_dense(w["M"], w["col_scale"], precision="f64" if var["item_f64"] else "f32")
         else:
             sc.set_item_matrix_csr(w["m_ptr"], w["m_idx"], w["m_val"], w["n_items"], w["col_scale"])
         sc.set_history_csr(w["h_ptr"], w["h_idx"], w["h_val"])
@@ -200,21 +231,39 @@ def build_workload(config, args, rank, dev):
         sc.set_factors(dw["U"], dw["V"], dw["ubase"], dw["ibase"])
         sc.set_exclusion_csr(dw["excl_ptr"], dw["excl_idx"])
         sc.set_truth_csr(dw["truth_ptr"], dw["truth_idx"])
-        m = min(args.cpu_sample_of(config), dw["n_users"])
+        m = min(var["cpu_sample"], dw["n_users"])
         w = synth.host_sample(dw, m)
         del dw
     else:
-        w = synth.make(config, n_users=args.users, n_items=args.items, seed=synth.CONFIGS[config][4] + 1000 * rank)
+        key = (config, var["k"], rank)
+        if key not in _HOST_WORKLOADS:
+            _HOST_WORKLOADS.clear()
+            _HOST_WORKLOADS[key] = synth.make(config, n_users=args.users, n_items=args.items,
+                                              seed=synth.CONFIGS[config][4] + 1000 * rank, k=var["k"])
+        w = _HOST_WORKLOADS[key]
         sc.set_factors(w["U"], w["V"], w["ubase"], w["ibase"])
         sc.set_exclusion_csr(w["excl_ptr"], w["excl_idx"])
         sc.set_truth_csr(w["truth_ptr"], w["truth_idx"])
     return sc, w
 
 
-def run_config(config, args, steps, warmup, world, rank, dev, D, with_cpu, auc=False):
-    """Time `steps` passes of the hot path over this rank's users of `config`; rank 0 returns the result fields."""
+def variant(args, config, **over):
+    """What one timed entry runs: list length, AUC, the float64 item matrix, a factor dimension other than the
+    configuration's, the size of the CPU sample."""
+    v = dict(topk=args.topk, auc=False, item_f64=False, k=None,
+             cpu_sample=args.cpu_sample if args.cpu_sample is not None else
+             {"c2_wmf_ml20m": 65536, "c3_mf_shard": 2048}.get(config, 16384))
+    v.update(over)
+    return v
+
+
+def run_config(config, args, steps, warmup, world, rank, dev, D, with_cpu, var):
+    """Time `steps` passes of the hot path over this rank's users of `config` (variant `var`); rank 0 returns the
+    result fields."""
     import torch
-    sc, w = build_workload(config, args, rank, dev)
+    from recommenders_amd import synth
+    TOPK, auc, item_f64 = var["topk"], var["auc"], var["item_f64"]
+    sc, w = build_workload(config, args, rank, dev, var)
     item_model = w.get("M", None) is not None or w.get("m_ptr", None) is not None
     n = w["n_users"]
     users = torch.arange(n, dtype=torch.int32, device=dev)
@@ -287,10 +336,10 @@ def run_config(config, args, steps, warmup, world, rank, dev, D, with_cpu, auc=F
     sums = sums.cpu().numpy()
     avg_ms = kern_ms / max(launches, 1)
     traffic, traffic_source = measured_traffic(config, n, w["n_items"])
-    if args.item_f64 and config in synth.ITEM_CONFIGS:
+    if (item_f64 and config in synth.ITEM_CONFIGS) or auc or TOPK != 10 or var["k"] is not None:
         traffic, traffic_source = None, None                      # the committed counter pass is the fp32 matrix
     if item_model:
-        bytes_per_launch = item_algorithmic_bytes(w) * (2.0 if (args.item_f64 and w["M"] is not None) else 1.0)   # fp64 rows: 8 B per entry
+        bytes_per_launch = item_algorithmic_bytes(w) * (2.0 if (item_f64 and w["M"] is not None) else 1.0)   # fp64 rows: 8 B per entry
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
         dense = w["M"] is not None
         kind = "EASE-style dense item-item B" if dense else "RP3-beta-style sparse item-item W"
@@ -305,8 +354,7 @@ def run_config(config, args, steps, warmup, world, rank, dev, D, with_cpu, auc=F
         if not dense:
             # the HBM roof is the contract's statement for this byte-moving path; what limits the kernel is instruction
             # issue (constants of the committed counter run, like `traffic`)
-            roof["limiter"] = ("VALU issue: 65 % of the CU's VALU issue slots, LDS pipe 25 % busy, 59 % of wave-cycles "
-                               "waiting (profiles/r02_c5_sq_counters.json)")
+            roof["limiter"] = "see profiles/r03_c5_sq_counters.json (round 2's hash-pass kernel: VALU issue, profiles/r02_c5_sq_counters.json)"
         cfg = {"workload": workload, "users_per_gpu": n, "items": w["n_items"], "topk": TOPK,
                "parallelism": f"users sharded x{world}, item matrix replicated"}
     else:
@@ -328,7 +376,7 @@ def run_config(config, args, steps, warmup, world, rank, dev, D, with_cpu, auc=F
         "warmup": warmup,
         "ms_per_step": 1e3 * dt / steps,
         "scaling": "weak",
-        "dtype": "f64" if (args.item_f64 and config in synth.ITEM_CONFIGS and w.get("M") is not None) else "f32",
+        "dtype": "f64" if (item_f64 and config in synth.ITEM_CONFIGS and w.get("M") is not None) else "f32",
         "data": "synthetic",
         "config": cfg,
         "roofline": roof,
@@ -346,16 +394,23 @@ def run_config(config, args, steps, warmup, world, rank, dev, D, with_cpu, auc=F
         out["wide_path"] = {"overflow_users": sc.wide_overflows(), "users": wu, "candidates_per_user": wc / max(wu, 1),
                             "kept_per_user": wk / max(wu, 1)}
     if with_cpu:
-        m = min(args.cpu_sample_of(config), n, w.get("host_rows", n))
+        m = min(var["cpu_sample"], n, w.get("host_rows", n))
+        o_met = None
         if item_model:
             shift = sc.item_fixed_point_shift() if w["M"] is None else 0
-            base, o_ids, _, _ = cpu_baseline_item(w, m, shift)
+            if item_f64 and w["M"] is not None:
+                base, o_ids = cpu_baseline_item_f64(w, m, TOPK)
+            else:
+                base, o_ids, _, _ = cpu_baseline_item(w, m, shift, TOPK)
         else:
-            base, o_ids, _, _ = cpu_baseline(w, m, sc.chain_order())
-            if config == "c2_wmf_ml20m":
+            base, o_ids, o_met, o_ev = cpu_baseline(w, m, sc.chain_order(), TOPK, want_auc=auc)
+            if config == "c2_wmf_ml20m" and var["k"] is None and not auc and TOPK == 10:
                 out["cpu_baseline_strong"] = cpu_strong(w, min(2048, n))
         out["cpu_baseline"] = base
         out["parity_on_cpu_sample"] = {"users": m, "top10_ids_equal" if TOPK == 10 else f"top{TOPK}_ids_equal": bool((h_ids2[(step_no[0] - 1) & 1][:m].numpy() == o_ids).all())}
+        if auc and o_met is not None:
+            ev = o_ev.astype(bool)
+            out["parity_on_cpu_sample"]["auc_equal"] = bool((auc_out[:m].cpu().numpy()[ev] == o_met[ev][:, -1]).all())
     sc.close()
     return out
 
@@ -376,19 +431,12 @@ def main():
     ap.add_argument("--item-f64", action="store_true", help="c4_ease_mind variant: float64 item matrix and sums (twice the bytes; use --no-cpu)")
     ap.add_argument("--dev", default="", help="development only: comma-separated library options name=value (debug_mode, chunks, "
                     "target_blocks, pair_max, wide_chunk_cap, ...) set on every engine; the library itself reads no environment variable")
+    ap.add_argument("--k", type=int, default=None, help="factor dimension other than the configuration's (c2 shape with k = 200: the reference's WMF default)")
     ap.add_argument("--auc", action="store_true", help="second variant of SURVEY.md 8d: also AUC (dense score rows + ifr_auc_dense)")
     args = ap.parse_args()
-    global TOPK
-    TOPK = args.topk
 
     import torch
     import torch.distributed as dist
-
-    def cpu_sample_of(config):
-        if args.cpu_sample is not None:
-            return args.cpu_sample
-        return {"c2_wmf_ml20m": 65536, "c3_mf_shard": 2048}.get(config, 16384)
-    args.cpu_sample_of = cpu_sample_of
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -407,16 +455,29 @@ def main():
 
     headline = args.config or "c2_wmf_ml20m"
     with_cpu = world == 1 and not args.no_cpu
-    res = run_config(headline, args, args.steps, args.warmup, world, rank, dev, D, with_cpu, auc=args.auc)
+    res = run_config(headline, args, args.steps, args.warmup, world, rank, dev, D, with_cpu,
+                     variant(args, headline, auc=args.auc, item_f64=args.item_f64, k=args.k))
     extras = []
-    if args.config is None and not args.no_extra and args.users is None and args.items is None:
-        # (config, steps, warm-up): bounded so that the whole default run stays within a few minutes
-        plan = [("c3_mf_shard", 2, 1)] + ([("c4_ease_mind", 3, 1), ("c5_rp3_ebnerd", 3, 1)] if world == 1 else [])
-        for cfg_name, k_steps, k_warm in plan:
+    if args.config is None and not args.no_extra and args.users is None and args.items is None and args.topk == 10 \
+            and not args.auc and args.k is None:
+        # (name, config, steps, warm-up, variant): bounded so that the whole default run stays within a few minutes.
+        # The C2 variants come first (they reuse the headline's host workload): every number DESIGN.md quotes for a
+        # variant of the path is measured by the driver's own run, with its own roofline and CPU parity sample.
+        plan = []
+        if world == 1:
+            plan += [("c2_auc", "c2_wmf_ml20m", 5, 2, dict(auc=True, cpu_sample=4096)),
+                     ("c2_top100", "c2_wmf_ml20m", 5, 2, dict(topk=100, cpu_sample=4096)),
+                     ("c2_k200", "c2_wmf_ml20m", 5, 2, dict(k=200, cpu_sample=4096))]
+        plan += [("c3_mf_shard", "c3_mf_shard", 2, 1, {})]
+        if world == 1:
+            plan += [("c4_ease_mind", "c4_ease_mind", 3, 1, {}),
+                     ("c4_ease_mind_f64", "c4_ease_mind", 2, 1, dict(item_f64=True, cpu_sample=512)),
+                     ("c5_rp3_ebnerd", "c5_rp3_ebnerd", 3, 1, {})]
+        for name, cfg_name, k_steps, k_warm, over in plan:
             torch.cuda.empty_cache()
-            r = run_config(cfg_name, args, k_steps, k_warm, world, rank, dev, D, with_cpu)
+            r = run_config(cfg_name, args, k_steps, k_warm, world, rank, dev, D, with_cpu, variant(args, cfg_name, **over))
             if r is not None:
-                r["name"] = cfg_name
+                r["name"] = name
                 extras.append(r)
     if rank == 0:
         out = {"metric": "users ranked/sec (full-catalogue top-10 + NDCG/Recall)"}

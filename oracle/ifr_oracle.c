@@ -200,6 +200,68 @@ double orc_auc(const float *scores, int n_items, const int32_t *excl, int n_excl
     return (double)wins / ((double)n_pos * (double)n_neg);
 }
 
+/* The same two functions on float64 score rows: the reference ranks the float64 scores of its item-item models
+ * directly (recommender.py:643-652 on recom_ease.py:123-124 / graph_recommender.py:104-117 outputs).  The library's CSR
+ * path accumulates exact fixed-point sums; scaled back to float64 they are exact, and this is the order it ranks in.
+ * out_scores: the winners' scores rounded once to fp32. */
+static inline int orc_beats64(double s, int32_t id, double s2, int32_t id2)
+{
+    return (s > s2) || (s == s2 && id < id2);
+}
+
+int orc_rank_topk64(const double *scores, int n_items, const int32_t *excl, int n_excl,
+                    int K, int32_t *out_ids, float *out_scores)
+{
+    int n_cand = 0, filled = 0, e = 0;
+    double *best = (double *)malloc(sizeof(double) * (size_t)(K > 0 ? K : 1));
+    for (int i = 0; i < n_items; ++i) {
+        while (e < n_excl && excl[e] < i) ++e;
+        if (e < n_excl && excl[e] == i) continue;
+        ++n_cand;
+        double s = scores[i];
+        if (s != s) continue;                       /* NaN never ranks */
+        if (filled == K && !orc_beats64(s, i, best[K - 1], out_ids[K - 1])) continue;
+        int pos = filled < K ? filled : K - 1;
+        while (pos > 0 && orc_beats64(s, i, best[pos - 1], out_ids[pos - 1])) {
+            best[pos] = best[pos - 1]; out_ids[pos] = out_ids[pos - 1]; --pos;
+        }
+        best[pos] = s; out_ids[pos] = i;
+        if (filled < K) ++filled;
+    }
+    for (int i = 0; i < filled; ++i) out_scores[i] = (float)best[i];
+    for (int i = filled; i < K; ++i) { out_ids[i] = -1; out_scores[i] = -INFINITY; }
+    free(best);
+    return n_cand;
+}
+
+double orc_auc64(const double *scores, int n_items, const int32_t *excl, int n_excl,
+                 const int32_t *pos, int n_pos)
+{
+    if (n_pos == 0) return NAN;
+    double *ps = (double *)malloc(sizeof(double) * (size_t)n_pos);
+    for (int i = 0; i < n_pos; ++i) ps[i] = scores[pos[i]];
+    for (int i = 1; i < n_pos; ++i) {
+        double x = ps[i]; int j = i;
+        while (j > 0 && ps[j - 1] > x) { ps[j] = ps[j - 1]; --j; }
+        ps[j] = x;
+    }
+    uint64_t wins = 0, n_neg = 0;
+    int e = 0, p = 0;
+    for (int i = 0; i < n_items; ++i) {
+        while (e < n_excl && excl[e] < i) ++e;
+        while (p < n_pos && pos[p] < i) ++p;
+        if (p < n_pos && pos[p] == i) continue;
+        if (e < n_excl && excl[e] == i) continue;
+        ++n_neg;
+        double s = scores[i];
+        int lo = 0, hi = n_pos;
+        while (lo < hi) { int mid = (lo + hi) >> 1; if (ps[mid] > s) hi = mid; else lo = mid + 1; }
+        wins += (uint64_t)(n_pos - lo);
+    }
+    free(ps);
+    return (double)wins / ((double)n_pos * (double)n_neg);
+}
+
 /* ------------------------------------------------------------------ */
 /* a9: ranking_eval hot loop (eval_methods/base_method.py:253-303) for  */
 /* factor models, one iteration per listed user.  CSR rows are already  */
@@ -307,10 +369,18 @@ void orc_score_item_dense_f64(const double *M, int64_t ld, int n_items,
     }
 }
 
-/* returns 0, or -1 if a fixed-point sum left the 62-bit range the shift must guarantee */
+/* Fixed-point accumulation of a CSR item matrix (include/ifr.h, ifr_set_item_matrix_csr): every product x * M' is
+ * exact in float64, scaled by 2^shift, rounded to the nearest-even integer and summed as an integer -- order-free.  The
+ * shift keeps every partial sum below 2^52, so the sum scaled back to float64 (out64) is exact; out = that rounded once
+ * to fp32.  A zero sum still meets the column scale (0 * inf = NaN like the reference).
+ * returns 0, or -1 if a sum left the 52-bit range the shift must guarantee */
 int orc_score_item_csr(const int64_t *m_ptr, const int32_t *m_idx, const float *m_val, int n_items,
                        const int32_t *h_idx, const float *h_val, int n_hist,
-                       int shift, const float *col_scale, float *out)
+                       int shift, const float *col_scale, float *out);
+
+int orc_score_item_csr64(const int64_t *m_ptr, const int32_t *m_idx, const float *m_val, int n_items,
+                         const int32_t *h_idx, const float *h_val, int n_hist,
+                         int shift, const float *col_scale, double *out64, float *out)
 {
     int64_t *acc = (int64_t *)calloc((size_t)(n_items > 0 ? n_items : 1), sizeof(int64_t));
     int rc = 0;
@@ -321,15 +391,24 @@ int orc_score_item_csr(const int64_t *m_ptr, const int32_t *m_idx, const float *
             const float w = col_scale ? m_val[q] * col_scale[m_idx[q]] : m_val[q];   /* folded, one fp32 rounding */
             const double pr = x * (double)w;                     /* exact */
             acc[m_idx[q]] += llrint(ldexp(pr, shift));           /* nearest even */
+            if (acc[m_idx[q]] > ((int64_t)1 << 52) || acc[m_idx[q]] < -((int64_t)1 << 52)) rc = -1;
         }
     }
     for (int c = 0; c < n_items; ++c) {
-        if (acc[c] > ((int64_t)1 << 62) || acc[c] < -((int64_t)1 << 62)) rc = -1;
-        const float s = (float)ldexp((double)acc[c], -shift);
-        out[c] = (col_scale && s == 0.0f) ? s * col_scale[c] : s;    /* 0 * inf = NaN like the reference */
+        double s = ldexp((double)acc[c], -shift);                /* exact: |acc| < 2^52 */
+        if (s == 0.0) s = col_scale ? 0.0 * (double)col_scale[c] : 0.0;
+        if (out64) out64[c] = s;
+        if (out) out[c] = (float)s;
     }
     free(acc);
     return rc;
+}
+
+int orc_score_item_csr(const int64_t *m_ptr, const int32_t *m_idx, const float *m_val, int n_items,
+                       const int32_t *h_idx, const float *h_val, int n_hist,
+                       int shift, const float *col_scale, float *out)
+{
+    return orc_score_item_csr64(m_ptr, m_idx, m_val, n_items, h_idx, h_val, n_hist, shift, col_scale, NULL, out);
 }
 
 /* a9 for item-item models: the per-user loop of ranking_eval (base_method.py:253-303) with the   */
@@ -354,6 +433,7 @@ int orc_ranking_eval_item(
 #endif
     {
         float *scores = (float *)malloc(sizeof(float) * (size_t)n_items);
+        double *scores64 = M ? NULL : (double *)malloc(sizeof(double) * (size_t)n_items);   /* CSR: ranked on the exact sums */
 #ifdef _OPENMP
 #pragma omp for schedule(dynamic, 4)
 #endif
@@ -368,9 +448,14 @@ int orc_ranking_eval_item(
             int32_t *ids = out_ids + (size_t)i * kmax;
             float *sc = out_scores + (size_t)i * kmax;
             double *m = out_metrics + (size_t)i * stride;
-            if (M) orc_score_item_dense(M, ld, n_items, hi, hv, n_h, col_scale, scores);
-            else if (orc_score_item_csr(m_ptr, m_idx, m_val, n_items, hi, hv, n_h, shift, col_scale, scores)) bad = 1;
-            int n_cand = orc_rank_topk(scores, n_items, ex, n_ex, kmax, ids, sc);
+            int n_cand;
+            if (M) {
+                orc_score_item_dense(M, ld, n_items, hi, hv, n_h, col_scale, scores);
+                n_cand = orc_rank_topk(scores, n_items, ex, n_ex, kmax, ids, sc);
+            } else {
+                if (orc_score_item_csr64(m_ptr, m_idx, m_val, n_items, hi, hv, n_h, shift, col_scale, scores64, scores)) bad = 1;
+                n_cand = orc_rank_topk64(scores64, n_items, ex, n_ex, kmax, ids, sc);
+            }
             evaluated[i] = n_pos > 0;
             if (n_pos == 0) {
                 for (int j = 0; j < stride; ++j) m[j] = NAN;
@@ -379,9 +464,11 @@ int orc_ranking_eval_item(
             int n_ranked = kmax < n_cand ? kmax : n_cand;
             for (int j = 0; j < n_k; ++j)
                 orc_metrics_at_k(ids, n_ranked, n_cand, pos, n_pos, ks[j], m + 3 * j);
-            m[n_k * 3] = want_auc ? orc_auc(scores, n_items, ex, n_ex, pos, n_pos) : NAN;
+            m[n_k * 3] = !want_auc ? NAN : (M ? orc_auc(scores, n_items, ex, n_ex, pos, n_pos)
+                                              : orc_auc64(scores64, n_items, ex, n_ex, pos, n_pos));
         }
         free(scores);
+        free(scores64);
     }
     return bad ? -1 : 0;
 }

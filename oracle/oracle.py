@@ -405,11 +405,11 @@ def c_score_item_dense(M, h_idx, h_val, col_scale=None):
 def c_score_item_dense_f64(M, h_idx, h_val, col_scale=None):
     """orc_score_item_dense_f64: fp64 fma chain over the history in order, then * col_scale in fp64.
     Returns (float64 scores, the same rounded once to fp32)."""
-    M = np.ascontiguousarray(M, np.float64)
+    M = np.ascontiguousarray(M, np.float64)                 # [rows, n_items]: square, or only the rows h_idx names
     h_idx, h_val, cs = _i32(h_idx), _f32(h_val), _f32(col_scale)
-    out = np.empty(M.shape[0], np.float64)
-    out32 = np.empty(M.shape[0], np.float32)
-    c_lib().orc_score_item_dense_f64(_p(M, ctypes.c_double), ctypes.c_int64(M.shape[1]), M.shape[0],
+    out = np.empty(M.shape[1], np.float64)
+    out32 = np.empty(M.shape[1], np.float32)
+    c_lib().orc_score_item_dense_f64(_p(M, ctypes.c_double), ctypes.c_int64(M.shape[1]), M.shape[1],
                                      _p(h_idx, ctypes.c_int32), _p(h_val, ctypes.c_float), len(h_idx),
                                      _p(cs, ctypes.c_float), _p(out, ctypes.c_double), _p(out32, ctypes.c_float))
     return out, out32
@@ -424,7 +424,20 @@ def c_score_item_csr(m_ptr, m_idx, m_val, n_items, h_idx, h_val, shift, col_scal
                                     int(n_items), _p(h_idx, ctypes.c_int32), _p(h_val, ctypes.c_float), len(h_idx),
                                     int(shift), _p(cs, ctypes.c_float), _p(out, ctypes.c_float))
     if rc != 0:
-        raise OverflowError("fixed-point sum left the 62-bit range: shift too large for these inputs")
+        raise OverflowError("fixed-point sum left the 52-bit range: shift too large for these inputs")
+    return out
+
+
+def c_score_item_csr64(m_ptr, m_idx, m_val, n_items, h_idx, h_val, shift, col_scale=None):
+    """orc_score_item_csr64: the exact fixed-point sums scaled back to float64 (what the library's CSR path ranks)."""
+    m_ptr, m_idx, m_val = _i64(m_ptr), _i32(m_idx), _f32(m_val)
+    h_idx, h_val, cs = _i32(h_idx), _f32(h_val), _f32(col_scale)
+    out = np.empty(n_items, np.float64)
+    rc = c_lib().orc_score_item_csr64(_p(m_ptr, ctypes.c_int64), _p(m_idx, ctypes.c_int32), _p(m_val, ctypes.c_float),
+                                      int(n_items), _p(h_idx, ctypes.c_int32), _p(h_val, ctypes.c_float), len(h_idx),
+                                      int(shift), _p(cs, ctypes.c_float), _p(out, ctypes.c_double), None)
+    if rc != 0:
+        raise OverflowError("fixed-point sum left the 52-bit range: shift too large for these inputs")
     return out
 
 
@@ -461,14 +474,14 @@ def c_ranking_eval_item(M, m_csr, shift, n_items, col_scale, h_ptr, h_idx, h_val
         _p(ids, ctypes.c_int32), _p(sc, ctypes.c_float), _p(met, ctypes.c_double), _p(ev, ctypes.c_int32),
         int(n_threads))
     if rc != 0:
-        raise OverflowError("fixed-point sum left the 62-bit range")
+        raise OverflowError("fixed-point sum left the 52-bit range")
     return ids, sc, met, ev
 
 
 def item_fixed_point_shift(m_val, h_ptr, h_val, m_idx=None, col_scale=None):
     """The shift rule documented in include/ifr.h (ifr_item_fixed_point_shift): the largest power of
-    two such that max|M'| * max_u sum_j |x_uj| * 1.001 * 2^shift <= 2^61, M' = the values with the
-    column scale folded in."""
+    two such that max|M'| * max_u sum_j |x_uj| * 1.001 * 2^shift <= 2^51, M' = the values with the
+    column scale folded in (every product and partial sum then is an integer below 2^51: exact in int64 and in float64)."""
     import math
     m_val = np.asarray(m_val, np.float32)
     if col_scale is not None:
@@ -481,7 +494,7 @@ def item_fixed_point_shift(m_val, h_ptr, h_val, m_idx=None, col_scale=None):
     if not bound > 0.0:
         return 0
     _, e = math.frexp(bound)
-    return max(-960, min(960, 61 - e))
+    return max(-960, min(960, 51 - e))
 
 
 def rp3_model_arrays(train_csr, beta):

@@ -80,6 +80,7 @@ struct ifr_handle_s {
     double *iiM64 = nullptr;     // dense item matrix of the fp64 scoring option (then iiM is null)
     int opt_item_f64 = 0;        // ifr_fit_ease installs B in fp64
     int64_t *ii_cptr = nullptr; int32_t *ii_idx = nullptr; float *ii_val = nullptr; int64_t ii_nnz = 0;
+    uint2 *ii_pair = nullptr;    // CSR entries as interleaved (column, value) pairs: what the CSR top-K kernel streams
     float *ii_pen = nullptr;
     int ii_chunks = 0;
     float ii_maxabs = 0.f;
@@ -124,7 +125,7 @@ struct ifr_handle_s {
     int opt_pair_topk = 1;       // 16 < K <= 32 of a dot-product model: two 16-lists per user and item chunk + loss check at the
                                  // merge (0: the candidate-buffer path like K > 32)
     int opt_debug = 0;           // dev-only kernel ablation mode (see TopkParams::dbg)
-    int opt_csr_pass = 0;        // dev/test: entries per hash pass of the CSR top-K kernel (0 = the kernel's capacity)
+    int opt_csr_pass = 0;        // test: candidate buffer entries of the CSR top-K kernel (0 = all; small values force its exact argmax fallback)
     int64_t opt_catalogue = 0;   // items the dense-row consumers rank (0 = n_items; > n_items: items unknown to the model)
     // profiling
     bool prof = false;
@@ -295,7 +296,7 @@ int64_t catalogue_items(ifr_handle h) { return h->opt_catalogue > h->n_items ? h
 
 void clear_item_model(ifr_handle h)
 {
-    dfree(h->iiM); dfree(h->iiM64); dfree(h->ii_cptr); dfree(h->ii_idx); dfree(h->ii_val); dfree(h->ii_pen);
+    dfree(h->iiM); dfree(h->iiM64); dfree(h->ii_cptr); dfree(h->ii_idx); dfree(h->ii_val); dfree(h->ii_pen); dfree(h->ii_pair);
     dfree(h->hs_ptr); dfree(h->hs_idx); dfree(h->hs_val);
     h->ii_ld = 0; h->ii_nnz = 0; h->ii_chunks = 0; h->ii_maxabs = 0.f;
     h->hs_rows = 0; h->hs_nnz = 0; h->hs_l1max = 0.f;
@@ -331,14 +332,16 @@ int set_col_scale(ifr_handle h, const float *col_scale, int64_t n_items, int64_t
     return IFR_OK;
 }
 
-// 2^shift: the largest power of two for which |sum_j x_uj M[j,c]| * 2^shift <= 2^61 for every user
+// 2^shift: the largest power of two for which sum_j |x_uj M[j,c]| * 2^shift <= 2^51 for every user: every product and
+// every partial sum then is an integer below 2^51 in magnitude -- exact in int64 AND in fp64, whose adds therefore do not
+// round (the top-K kernel accumulates integer-valued doubles with ds_add_f64; round 2 used 2^61 and int64 only)
 int fixed_point_shift(ifr_handle h)
 {
     const double bound = (double)h->ii_maxabs * (double)h->hs_l1max * 1.001;
     if (!(bound > 0.0)) return 0;
     int e = 0;
     (void)std::frexp(bound, &e);                 // bound <= 2^e
-    return std::max(-960, std::min(960, 61 - e));
+    return std::max(-960, std::min(960, 51 - e));
 }
 
 int read_flag_and_max(ifr_handle h, const void *dev, uint32_t *out)
@@ -386,7 +389,7 @@ int ifr_destroy(ifr_handle h)
     dfree(h->U); dfree(h->V); dfree(h->ibase); dfree(h->ubase);
     dfree(h->ex_ptr); dfree(h->ex_idx); dfree(h->ex_cnt); dfree(h->ex_pair);
     dfree(h->tr_ptr); dfree(h->tr_idx); dfree(h->discount);
-    dfree(h->iiM); dfree(h->iiM64); dfree(h->ii_cptr); dfree(h->ii_idx); dfree(h->ii_val); dfree(h->ii_pen);
+    dfree(h->iiM); dfree(h->iiM64); dfree(h->ii_cptr); dfree(h->ii_idx); dfree(h->ii_val); dfree(h->ii_pen); dfree(h->ii_pair);
     dfree(h->hs_ptr); dfree(h->hs_idx); dfree(h->hs_val);
     dfree(h->ws_part); dfree(h->ws_met); dfree(h->ws_sort);
     ifr::ease_release(&h->rocblas);
@@ -417,7 +420,7 @@ int ifr_set_option(ifr_handle h, const char *name, int64_t value)
 #endif
         h->opt_debug = (int)value;
     }
-    else if (!strcmp(name, "csr_pass_entries")) h->opt_csr_pass = (int)std::max<int64_t>(0, std::min<int64_t>(value, ifr::item_sparse_pass_capacity()));
+    else if (!strcmp(name, "csr_cand_cap")) h->opt_csr_pass = value <= 0 ? 0 : (int)std::max<int64_t>(ifr::item_sparse_min_capacity(), std::min<int64_t>(value, ifr::item_sparse_pass_capacity()));
     else if (!strcmp(name, "catalogue_items")) {
         if (value != 0 && (value < h->n_items || value > (int64_t)1 << 30))
             return fail(h, IFR_ERR_ARG, "catalogue_items must be 0 or >= the model's n_items");
@@ -700,6 +703,12 @@ int ifr_set_item_matrix_csr(ifr_handle h, const int64_t *indptr, const int32_t *
             if (nnz > 0) lrc = ifr::launch_scale_csr_values(h->ii_val, h->ii_idx, nnz, h->ii_pen, 0);
         }
         if (!lrc && nnz > 0) lrc = ifr::launch_absmax(h->ii_val, nnz, (uint32_t *)d_flags + 1, 0);
+        if (!lrc) {                              // the entries once more as (column, value) pairs, pad included
+            const int64_t np = nnz + ifr::item_csr_pad();
+            if (hipMalloc((void **)&h->ii_pair, sizeof(uint2) * np) != hipSuccess ||
+                hipMemset(h->ii_pair, 0, sizeof(uint2) * np) != hipSuccess) lrc = -4;
+            else if (nnz > 0) lrc = ifr::launch_interleave_csr(h->ii_idx, h->ii_val, nnz, h->ii_pair, 0);
+        }
     }
     if (lrc || hipDeviceSynchronize() != hipSuccess ||
         hipMemcpy(flags, d_flags, sizeof(flags), hipMemcpyDeviceToHost) != hipSuccess) {
@@ -820,7 +829,7 @@ static int item_item_params(ifr_handle h, const int32_t *user_ids, int64_t n, if
     if (!h->hs_ptr) return fail(h, IFR_ERR_STATE, "item-item model: histories not set (ifr_set_history_csr)");
     memset(p, 0, sizeof(*p));
     p->M = h->iiM; p->M64 = h->iiM64; p->ldm = h->ii_ld;
-    p->cptr = h->ii_cptr; p->m_idx = h->ii_idx; p->m_val = h->ii_val; p->m_nnz = h->ii_nnz;
+    p->cptr = h->ii_cptr; p->m_idx = h->ii_idx; p->m_val = h->ii_val; p->m_pair = h->ii_pair; p->m_nnz = h->ii_nnz;
     p->fx_shift = h->mode == MODE_ITEM_CSR ? fixed_point_shift(h) : 0;
     p->dbg = h->opt_debug;
     p->sp_cap = h->opt_csr_pass > 0 ? h->opt_csr_pass : ifr::item_sparse_pass_capacity();
@@ -859,8 +868,6 @@ static int rank_topk_item_item(ifr_handle h, const int32_t *user_ids, int64_t n,
     p.K = K; p.KL = KL;
     std::pair<hipEvent_t, hipEvent_t> ev;
     if (h->mode == MODE_ITEM_CSR) {                  // one workgroup per user, final lists written directly
-        if (p.n_chunks > ifr::item_sparse_max_chunks())
-            return fail(h, IFR_ERR_ARG, "ifr_rank_topk: CSR item matrix: catalogue beyond 2097152 items (use the dense-row entry points)");
         rc = prof_begin(h, s, &ev);
         if (rc) return rc;
         if (ifr::launch_item_sparse_topk(p, out_ids, out_scores, s)) return fail(h, IFR_ERR_HIP, "ifr_rank_topk: item-item launch failed");
@@ -1403,8 +1410,8 @@ int ifr_score_dense(ifr_handle h, const int32_t *user_ids, int64_t n, float *out
 int ifr_score_dense_f64(ifr_handle h, const int32_t *user_ids, int64_t n, double *out, int64_t ld, void *stream)
 {
     if (!h) return IFR_ERR_ARG;
-    if (h->mode != MODE_ITEM_DENSE || !h->iiM64)
-        return fail(h, IFR_ERR_STATE, "ifr_score_dense_f64: needs an fp64 dense item matrix (ifr_set_item_matrix_dense_f64, or ifr_fit_ease with option item_f64)");
+    if (!((h->mode == MODE_ITEM_DENSE && h->iiM64) || h->mode == MODE_ITEM_CSR))
+        return fail(h, IFR_ERR_STATE, "ifr_score_dense_f64: needs an fp64 dense item matrix (ifr_set_item_matrix_dense_f64, or ifr_fit_ease with option item_f64) or a CSR item matrix");
     if (n == 0) return IFR_OK;
     if (!user_ids || !out || n < 0 || ld < h->n_items) return fail(h, IFR_ERR_ARG, "ifr_score_dense_f64: null argument or ld < n_items");
     if (n > (int64_t)1 << 24) return fail(h, IFR_ERR_ARG, "ifr_score_dense_f64: more than 2^24 users in one call");
@@ -1413,7 +1420,7 @@ int ifr_score_dense_f64(ifr_handle h, const int32_t *user_ids, int64_t n, double
     int rc = item_item_params(h, user_ids, n, &ip);
     if (rc) return rc;
     ip.out64 = out; ip.ld = ld;
-    if (ifr::launch_item_item(ip, false, false, (hipStream_t)stream)) return fail(h, IFR_ERR_HIP, "ifr_score_dense_f64: launch failed");
+    if (ifr::launch_item_item(ip, h->mode == MODE_ITEM_CSR, false, (hipStream_t)stream)) return fail(h, IFR_ERR_HIP, "ifr_score_dense_f64: launch failed");
     return IFR_OK;
 }
 
@@ -1510,10 +1517,6 @@ int ifr_debug_read_stamps(ifr_handle h, unsigned long long *out, int64_t cap, in
 {
     if (!h || !out || !n) return IFR_ERR_ARG;
     IFR_HIP(h, hipDeviceSynchronize());
-    if (h->mode == MODE_ITEM_CSR && cap >= 16) {          // the CSR top-K kernel's phase counters (make ABLATE=1)
-        *n = ifr::item_sparse_read_phases(out) == 0 ? 16 : 0;
-        return IFR_OK;
-    }
     *n = (int64_t)std::min<size_t>(h->dbg_stamp_count, (size_t)cap);
     if (*n > 0) IFR_HIP(h, hipMemcpy(out, h->ws_met, sizeof(unsigned long long) * (size_t)*n, hipMemcpyDeviceToHost));
     return IFR_OK;

@@ -12,10 +12,11 @@ struct ItemItemParams {
     const int64_t *cptr;         // sparse: [n_items][n_chunks + 1] entry positions per item chunk
     const int32_t *m_idx;        //         column of every entry
     const float *m_val;
+    const uint2 *m_pair;         //         the same entries as interleaved (column, value bits) pairs (top-K kernel)
     int64_t m_nnz;               //         entries in m_idx / m_val
     int fx_shift;                //         fixed-point scale 2^fx_shift
     int dbg;                     // dev-only ablation bits (handle option debug_mode)
-    int sp_cap;                  //         CSR top-K: entries one hash pass may hold (<= item_sparse_pass_capacity())
+    int sp_cap;                  //         CSR top-K: candidate buffer entries in use (item_sparse_min_capacity() .. item_sparse_pass_capacity())
     const float *pen;            // [>= n_chunks * chunk] column scale or null (CSR: already folded into m_val,
                                  // kept for the 0 * col_scale = NaN rule of exact zeros)
     const int64_t *h_ptr;        // history CSR
@@ -44,6 +45,7 @@ int launch_merge_topk_f64(const double *part_scores, const int32_t *part_ids, in
                           float *out_scores, hipStream_t stream);
 int launch_item_sparse_topk(const ItemItemParams &p, int32_t *out_ids, float *out_scores, hipStream_t stream);
 int item_sparse_pass_capacity();
+int item_sparse_min_capacity();
 int item_sparse_read_phases(unsigned long long *out16);   // dev build only (make ABLATE=1), else -1
 int item_sparse_max_chunks();
 int item_csr_pad();             // entries the CSR index / value arrays must be allocated past nnz
@@ -55,6 +57,7 @@ int launch_validate_csr(const int64_t *ptr, const int32_t *idx, int64_t n_rows, 
 int launch_build_chunk_ptr(const int64_t *ptr, const int32_t *idx, int64_t n_rows, int n_chunks, int chunk, int64_t *cptr,
                            hipStream_t s);
 int launch_scale_csr_values(float *val, const int32_t *idx, int64_t nnz, const float *col_scale, hipStream_t s);
+int launch_interleave_csr(const int32_t *idx, const float *val, int64_t n, uint2 *pair, hipStream_t s);
 int launch_absmax(const float *x, int64_t n, uint32_t *out, hipStream_t s);
 int launch_row_l1_max(const int64_t *ptr, const float *val, int64_t n_rows, uint32_t *out, hipStream_t s);
 

@@ -107,6 +107,22 @@ __global__ __launch_bounds__(II_BLOCK, 3) void item_item_kernel(ItemItemParams p
             }
         }
         __syncthreads();
+        if (!TOPK && p.out64 != nullptr) {
+            // fp64 rows of a CSR matrix: the exact fixed-point sum scaled back (|sum| < 2^52: nothing is rounded); a zero sum
+            // still meets the column scale (0 * inf = NaN like the reference)
+#pragma unroll
+            for (int q = 0; q < PASSES; ++q) {
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int col = col0 + q * II_PASS + v;
+                    if (col >= p.n_items) continue;
+                    double sd = ldexp((double)(long long)acc64[q * II_PASS + 4 * tid + v], -p.fx_shift);
+                    if (sd == 0.0) sd = p.pen != nullptr ? 0.0 * (double)p.pen[col] : 0.0;
+                    p.out64[i * p.ld + col] = sd;
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int q = 0; q < PASSES; ++q) {
 #pragma unroll
@@ -399,556 +415,537 @@ __global__ __launch_bounds__(II_BLOCK, 3) void item_item_kernel(ItemItemParams p
 }
 
 // ------------------------------------------------------------------------------------
-// CSR M, top-K: one workgroup per user with ONE running top-K list.  The user's catalogue is
-// swept in PASSES of consecutive item chunks; a pass takes as many chunks as hold at most
-// `sp_cap` (entry, exclusion) pairs of this user, found from the per-chunk entry positions
-// (cptr) summed over the history rows.  A typical user (a few thousand nonzeros in all its
-// history rows) is done in one to four passes instead of one per 4096-column chunk.
-//   plan       : Tc[c] = entries of all history rows + exclusions with column < c * 4096;
-//   hash pass  : the pass's entries are summed in an LDS hash table (open addressing, key =
-//                column + 1, 64-bit fixed-point value as above; the user's exclusions are
-//                entered first with a flag bit, entries that find a flagged key are dropped);
-//   dense pass : a single chunk with more than sp_cap entries falls back to 4096 direct-mapped
-//                64-bit accumulators + a touched bitmap in the same LDS;
-//   select     : every thread converts its table slots to (orderable score, ~item) keys in
-//                registers.  While the list is not full a lower bound of the K-th best comes from
-//                K rounds of a DPP wave maximum over the threads' best keys; keys above the bound
-//                (or above the list's K-th key) are appended behind a copy of the list and ranked
-//                by counting (keys are unique, larger = better);
-//   zeros      : columns no history row touches score exactly 0 * col_scale.  They only matter
-//                when the list ends up short or holds scores <= 0; only then a second sweep marks
-//                the touched columns per chunk and takes the K lowest untouched item ids.
+// CSR M, top-K (round 3): one workgroup per user sweeps the catalogue in WINDOWS of 4096 columns -- the granularity of
+// the per-row entry positions `cptr` built at set time -- and keeps ONE running top-K list.
+//
+//   accumulate : every history row's entries of the window (a contiguous segment: cptr[row][c] .. cptr[row][c + 1]) are
+//                added into 4096 DIRECT-MAPPED fp64 accumulators in LDS: no hashing, no probing, no key compares.
+//                The addend is the exact product x_uj * M'[j, c] * 2^shift rounded to the nearest-even INTEGER by one
+//                fma against 1.5 * 2^52 (three VALU instructions from the loaded value to the addend; round 2 converted
+//                to int64 in ~30).  The shift keeps every product and every partial sum below 2^51, so the fp64 adds
+//                (native ds_add_f64) are EXACT: the sum does not depend on the order in which the waves arrive, is
+//                bit-reproducible, and a CPU checker restates it with 64-bit integers (ifr_item_fixed_point_shift).
+//   exclusions : the user's excluded columns of the window are stored as a poison value (-2^60) that no sum can lift.
+//   scan       : every thread swaps its 16 accumulators for zero (one LDS exchange each: read and clear), so the table is
+//                clean for the next window; a max tree + ONE compare against the list's K-th sum decides whether the
+//                thread holds a candidate at all (after the first windows almost never).
+//   select     : in the EXACT domain -- candidates are (sum, column) pairs ordered by sum descending, column ascending;
+//                nothing is converted or rounded before it is ranked (only the K winners are scaled back and rounded to
+//                fp32 at the end).  New candidates go behind a copy of the list and are ranked by counting.  While the
+//                list is short, a lower bound of the window's K-th best comes from K rounds of a wave maximum over the
+//                threads' best sums.  A window with more candidates than the buffer holds (mass ties) is ranked by K
+//                rounds of an exact block-wide argmax over the register-resident sums instead.
+//   zeros      : columns whose sum is exactly 0 (no history row touches them, or the entries cancel) score
+//                0 * col_scale.  They only matter when the list ends up short or holds sums <= 0; only then a second
+//                sweep takes, in column order, the zero columns that still rank.
+// The work per user is |entries| + n_items / 64 wave-level slot visits: it follows the catalogue size as well as the
+// user's nonzeros (round 2's hash passes followed the nonzeros only, at ~250 VALU instructions per 64 entries).
 // ------------------------------------------------------------------------------------
-// make ABLATE=1 compiles the cumulative early exits (option "debug_mode" 101..105, timing only, tools/time_c5.py) into
-// item_sparse_topk_kernel; the product build leaves them out (they cost SGPRs and a scratch slot)
-#ifdef IFR_ABLATE
-constexpr bool SP_DEV = true;
-#else
-constexpr bool SP_DEV = false;
-#endif
-#ifdef IFR_ABLATE
-// dev: shader-clock cycles of thread 0 per phase, summed over workgroups (tools/time_c5.py prints them)
-static __device__ unsigned long long sp_phase[16];
-#define SP_STAMP(k) do { if (tid == 0 && (blockIdx.x & 63) == 0) { const long long now_ = clock64(); atomicAdd(&sp_phase[k], (unsigned long long)(now_ - sp_last)); sp_last = now_; } } while (0)
-#define SP_COUNT(k) do { if (tid == 0 && (blockIdx.x & 63) == 0) atomicAdd(&sp_phase[k], 1ull); } while (0)
-#else
-#define SP_STAMP(k) do { } while (0)
-#define SP_COUNT(k) do { } while (0)
-#endif
-constexpr int SP_CHUNK = II_SPARSE_PASSES * II_PASS;   // 4096 columns: granularity of cptr
-constexpr int SP_BLOCK = 512;                           // threads per user: three workgroups (6 waves/SIMD, <= 85 VGPRs) per CU
-constexpr int SP_SPT = 7;                               // hash slots per thread
-constexpr int SP_SLOTS = SP_BLOCK * SP_SPT;             // 3584 slots (43 KB): the kernel is latency bound, occupancy beats table size
-constexpr int SP_CAP = SP_SLOTS * 11 / 16;              // entries per hash pass (load <= 0.69; measured optimum 0.62-0.75)
-constexpr int SP_RAW = SP_SLOTS * 3 / 2;                // 64-bit words: values, then 32-bit keys
-constexpr int SP_DPT = (SP_CHUNK + SP_BLOCK - 1) / SP_BLOCK;   // dense pass: accumulators per thread
-constexpr int SP_REG = SP_SPT > SP_DPT ? SP_SPT : SP_DPT;
-constexpr int SP_HIST = 128;                            // history rows staged per round
-constexpr int SP_EXCAP = 256;                           // exclusion row entries kept in LDS
-constexpr int SP_MAXCH = 512;                           // item chunks (catalogue <= 2 097 152 items)
-constexpr int SP_NG = SP_BLOCK / II_GROUP;
-constexpr int SP_ZC = (SP_CHUNK + SP_BLOCK - 1) / SP_BLOCK;               // columns per thread in the zero sweep              // 16-lane groups per workgroup
-constexpr uint32_t SP_FLAG = 0x80000000u;               // key flag: excluded column
-static_assert(SP_RAW >= SP_CHUNK + 2 * (SP_CHUNK / 64) + 64, "dense pass accumulators + bitmaps must fit the table");
+constexpr int SP_CHUNK = II_SPARSE_PASSES * II_PASS;   // 4096 columns: granularity of cptr = one window
+constexpr int SD_BLOCK = 256;                           // threads per user
+constexpr int SD_SPT = SP_CHUNK / SD_BLOCK;             // 16 accumulators per thread
+constexpr int SD_HIST = 256;                            // history rows staged per round
+constexpr int SD_PRE = 3;                               // entries per lane prefetched one window ahead
+constexpr int SD_EXCAP = 256;                           // exclusion row entries kept in LDS
+constexpr int SD_CAND = 256;                            // candidate buffer: the list + new candidates of a window
+constexpr int SD_MAXK = 32;
+constexpr int SD_FLOOR_BITS = 18;                       // bits of the short-list bound (sign + exponent + 6 of the mantissa)
+constexpr int SD_LAZY = 24;                             // pending candidates that trigger a merge
+constexpr double SD_MAGIC = 6755399441055744.0;         // 1.5 * 2^52: x + MAGIC - MAGIC = x rounded to the nearest-even integer, |x| < 2^51
+constexpr double SD_POISON = -1152921504606846976.0;    // -2^60: an excluded column
+constexpr double SD_LIVE = -288230376151711744.0;       // -2^58: sums above are real (|sum| < 2^52)
 
-__device__ __forceinline__ uint32_t sp_float_key(float x)
+__device__ __forceinline__ bool sd_beats(double v, int c, double v2, int c2)
 {
-    const uint32_t b = __float_as_uint(x);
-    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+    return (v > v2) || (v == v2 && c < c2);
 }
-__device__ __forceinline__ float sp_key_float(uint32_t k)
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() fences global memory as well, and its acquire side made
+// the compiler drain every global load in flight (s_waitcnt vmcnt(0)) right after each barrier -- the loads this kernel
+// issues a window ahead precisely so that they stay in flight across the barriers.  Nothing here communicates through
+// global memory (inputs are read-only, a thread writes its own outputs at the end).
+__device__ __forceinline__ void sd_barrier()
 {
-    return __uint_as_float((k & 0x80000000u) ? (k ^ 0x80000000u) : ~k);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
-__device__ __forceinline__ unsigned long long sp_key(float s, int col)
+__device__ __forceinline__ double sd_wave_max(double v)
 {
-    return ((unsigned long long)sp_float_key(s) << 32) | (uint32_t)(~col);
-}
-__device__ __forceinline__ int sp_slot(int col)
-{
-    return (int)(((((uint32_t)col * 0x9E3779B1u) >> 16) * (uint32_t)SP_SLOTS) >> 16);
-}
-// Probe stride of a column (double hashing): 14 k + 1, k < 128 -- odd and = 1 mod 7, so coprime with SP_SLOTS = 2^9 * 7 and
-// every probe sequence visits every slot.  With a stride of 1 (linear probing) the longest probe sequence among a wave's
-// lanes -- which sets the number of probing rounds -- grows with the clusters; a key-dependent stride breaks them up.
-static_assert(SP_SLOTS == 512 * 7, "sp_step assumes SP_SLOTS = 2^9 * 7");
-__device__ __forceinline__ int sp_step(int col)
-{
-    const uint32_t h = ((uint32_t)col * 0x85EBCA6Bu) >> 25;          // 7 bits
-    return (int)(h * 14u + 1u);
-}
-__device__ __forceinline__ int sp_next(int slot, int step)
-{
-    slot += step;
-    return slot >= SP_SLOTS ? slot - SP_SLOTS : slot;
-}
-// maximum over the 64 lanes (DPP row shifts + row broadcasts), returned to every lane
-__device__ __forceinline__ uint32_t sp_wave_max(uint32_t v)
-{
-#define SP_DPP_MAX(ctrl) v = max(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, ctrl, 0xf, 0xf, false))
-    SP_DPP_MAX(0x111);   // row_shr:1
-    SP_DPP_MAX(0x112);   // row_shr:2
-    SP_DPP_MAX(0x114);   // row_shr:4
-    SP_DPP_MAX(0x118);   // row_shr:8   -> lane 15 of each row holds the row maximum
-    SP_DPP_MAX(0x142);   // row_bcast:15
-    SP_DPP_MAX(0x143);   // row_bcast:31 -> lane 63 holds the wave maximum
-#undef SP_DPP_MAX
-    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
-}
-// sum over each row of 16 lanes, valid in the row's last lane
-__device__ __forceinline__ int sp_row_sum(int v)
-{
-    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);
-    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);
-    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);
-    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v = fmax(v, __shfl_xor(v, off));
     return v;
 }
 
-constexpr size_t SP_LDS_BYTES = (size_t)SP_RAW * 8 + (SP_MAXCH + 1) * 8 + 2 * SP_HIST * 8 + 32 * 8 + 2 * SP_HIST * 4 +
-                                SP_EXCAP * 4 + (SP_BLOCK / 64) * 4 + 8;
-
-__global__ __launch_bounds__(SP_BLOCK, 6) void item_sparse_topk_kernel(ItemItemParams p, int32_t *out_ids,
-                                                                       float *out_scores)
+template <bool IDX32>
+__global__ __launch_bounds__(SD_BLOCK, 4) void item_sparse_topk_kernel(ItemItemParams p, int32_t *out_ids, float *out_scores)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char sp_lds[];   // > 64 KB: dynamic
-    unsigned long long *const raw = reinterpret_cast<unsigned long long *>(sp_lds);          // [SP_RAW] table / accumulators / merge keys
-    unsigned long long *const Tc = raw + SP_RAW;                                             // [SP_MAXCH + 1]
-    int64_t *const s0 = reinterpret_cast<int64_t *>(Tc + SP_MAXCH + 1);                      // [SP_HIST] current pass's segment
-    int64_t *const s1 = s0 + SP_HIST;                                                        // [SP_HIST]   of each staged row
-    unsigned long long *const top = reinterpret_cast<unsigned long long *>(s1 + SP_HIST);    // [32]
-    int *const hj = reinterpret_cast<int *>(top + 32);                                       // [SP_HIST]
-    float *const hx = reinterpret_cast<float *>(hj + SP_HIST);                               // [SP_HIST]
-    int *const exl = reinterpret_cast<int *>(hx + SP_HIST);                                  // [SP_EXCAP]
-    uint32_t *const wred = reinterpret_cast<uint32_t *>(exl + SP_EXCAP);                     // [SP_BLOCK / 64]
-    int &s_nq = *reinterpret_cast<int *>(wred + SP_BLOCK / 64);
-    int &s_cnt = *(&s_nq + 1);
-    unsigned long long *const vals = raw;                                    // [SP_SLOTS]
-    uint32_t *const keys = reinterpret_cast<uint32_t *>(raw + SP_SLOTS);     // [SP_SLOTS]
-    unsigned long long *const qkey = raw;                                    // merge keys (table is in registers by then)
-    uint32_t *const tbm = reinterpret_cast<uint32_t *>(raw + SP_RAW - 2 * (SP_CHUNK / 64));   // touched columns of a chunk
-    uint32_t *const xbm = tbm + SP_CHUNK / 32;                                                // excluded columns of a chunk
+    __shared__ __attribute__((aligned(16))) double tab[SP_CHUNK + 64];        // + a dummy slot per lane
+    __shared__ double xs[SD_HIST];                       // history weight * 2^shift
+    __shared__ int hj[SD_HIST];
+    __shared__ int exl[SD_EXCAP];
+    __shared__ double cand_v[SD_CAND];
+    __shared__ int cand_c[SD_CAND];
+    __shared__ double top_v[SD_MAXK];
+    __shared__ int top_c[SD_MAXK];
+    __shared__ double wred_v[SD_BLOCK / 64];
+    __shared__ int wred_c[SD_BLOCK / 64];
+    __shared__ uint32_t wred_n[SD_BLOCK / 64];
+    __shared__ int s_nq, s_cnt, s_dead;
 
-    const int tid = threadIdx.x;
-#ifdef IFR_ABLATE
-    long long sp_last = clock64();
-#endif
-    const int lane = tid & 63, wave = tid >> 6;
-    const int g = tid / II_GROUP, l = tid % II_GROUP;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t i = blockIdx.x;
     const int u = p.user_ids[i];
     const int K = p.K;
     const int nc1 = p.n_chunks + 1;
+    const int cap = p.sp_cap;                             // candidate buffer entries in use (<= SD_CAND; tests shrink it)
 
     int64_t hb = 0, he = 0, eb = 0, ee = 0;
     if (u >= 0 && u < p.h_rows) { hb = p.h_ptr[u]; he = p.h_ptr[u + 1]; }
     if (p.ex_ptr != nullptr && u >= 0 && u < p.ex_rows) { eb = p.ex_ptr[u]; ee = p.ex_ptr[u + 1]; }
     const int64_t n_ex = ee - eb;
-    const bool ex_lds = n_ex <= SP_EXCAP;
-    const bool single = (he - hb) <= SP_HIST;           // the whole history fits one staging round
+    const bool ex_lds = n_ex <= SD_EXCAP;
+    const bool single = (he - hb) <= SD_HIST;            // the whole history fits one staging round
     const int m1 = single ? (int)(he - hb) : 0;
 
-    for (int w = tid; w < SP_RAW; w += SP_BLOCK) raw[w] = 0ull;
-    for (int w = tid; w < nc1; w += SP_BLOCK) Tc[w] = 0ull;
-    if (ex_lds) for (int w = tid; w < (int)n_ex; w += SP_BLOCK) exl[w] = p.ex_idx[eb + w];
-    if (tid < 32) top[tid] = 0ull;
-    if (tid == 0) { s_nq = 0; s_cnt = 0; }
+    for (int w = tid; w < SP_CHUNK + 64; w += SD_BLOCK) tab[w] = 0.0;
+    if (ex_lds) for (int w = tid; w < (int)n_ex; w += SD_BLOCK) exl[w] = p.ex_idx[eb + w];
+    if (tid == 0) { s_nq = 0; s_cnt = 0; s_dead = 0; }
+    auto stage = [&](int64_t base, int m) {
+        for (int e = tid; e < m; e += SD_BLOCK) { hj[e] = p.h_idx[base + e]; xs[e] = ldexp((double)p.h_val[base + e], p.fx_shift); }
+    };
+    if (single) stage(hb, m1);
+    sd_barrier();
 
-    // first exclusion entry with column >= col (every thread searches; block-uniform for uniform col)
+    // first exclusion entry with column >= col
     auto ex_lower_bound = [&](int col) -> int64_t {
         int64_t lo = 0, hi = n_ex;
         if (ex_lds) { while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (exl[mid] < col) lo = mid + 1; else hi = mid; } }
         else { while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (p.ex_idx[eb + mid] < col) lo = mid + 1; else hi = mid; } }
         return lo;
     };
-    auto excluded = [&](int col) -> bool {
-        const int64_t lo = ex_lower_bound(col);
-        return lo < n_ex && (ex_lds ? exl[lo] : p.ex_idx[eb + lo]) == col;
-    };
-    // fn(col) for the user's exclusions with colA <= col < colB
-    auto for_exclusions = [&](int colA, int colB, auto &&fn) {
+    // the user's exclusions with colA <= col < colB become poison slots (stores race with the adds of the same window:
+    // either order leaves the slot far below every real sum)
+    auto poison = [&](int colA, int colB) __attribute__((always_inline)) {
         if (n_ex == 0) return;
         if (ex_lds) {
-            for (int w = tid; w < (int)n_ex; w += SP_BLOCK) { const int c = exl[w]; if (c >= colA && c < colB) fn(c); }
+            for (int w = tid; w < (int)n_ex; w += SD_BLOCK) { const int c = exl[w]; if (c >= colA && c < colB) tab[c - colA] = SD_POISON; }
         } else {
-            for (int64_t w = ex_lower_bound(colA) + tid; w < n_ex; w += SP_BLOCK) {
+            for (int64_t w = ex_lower_bound(colA) + tid; w < n_ex; w += SD_BLOCK) {
                 const int c = p.ex_idx[eb + w];
                 if (c >= colB) break;
-                fn(c);
+                tab[c - colA] = SD_POISON;
             }
         }
     };
-    // rows [base, base + m) of the history: item, weight and the entry range of chunks [ca, cb)
-    auto stage = [&](int64_t base, int m, int ca, int cb, bool load_rows) {
-        for (int e = tid; e < m; e += SP_BLOCK) {
-            int j;
-            if (load_rows) { j = p.h_idx[base + e]; hj[e] = j; hx[e] = p.h_val[base + e]; }
-            else j = hj[e];
-            const int64_t *cp = p.cptr + (int64_t)j * nc1;
-            s0[e] = cp[ca];
-            s1[e] = cp[cb];
-        }
-    };
-    // fn(cols[4], vals[4], ok[4], x) over the staged rows' segments: a 16-lane group per row, four
-    // strides of 16 entries in flight per lane
-    auto sweep = [&](int m, auto &&fn) {
-        const int gpr = m > 0 && m < SP_NG ? SP_NG / m : 1;     // lane groups per row (short histories)
-        const int step = 4 * II_GROUP * gpr;
-        for (int e = g / gpr; e < m; e += SP_NG / gpr) {
-            if (gpr > 1 && g >= gpr * m) break;                   // groups left over
-            const double x = ldexp((double)hx[e], p.fx_shift);
-            const int64_t q0 = s0[e] + (g % gpr) * (4 * II_GROUP) + l;
-            // entries left from this lane's first one; strides past the segment re-read its last entry of this
-            // lane and arrive with ok = false
-            int rem = (int)min(s1[e] - q0, (int64_t)0x7fffffff);
-            const int32_t *ip = p.m_idx + q0;
-            const float *vp = p.m_val + q0;
-            for (; rem > 0; rem -= step, ip += step, vp += step) {
-                int c[4];
-                float w[4];
-                bool ok[4];
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    ok[t] = t * II_GROUP < rem;
-                    const int o = min(t * II_GROUP, rem - 1);     // stay inside the segment's cache lines
-                    c[t] = ip[o];
-                    w[t] = vp[o];
-                }
-                fn(c, w, ok, x);
+    // rows [0, m) of the staged history: L lanes share a row's segment of window c
+    auto accumulate_rows = [&](int m, int c, int colA) __attribute__((always_inline)) {
+        int L = SD_BLOCK;
+        while (L > 1 && SD_BLOCK / L < m) L >>= 1;        // largest power of two with (SD_BLOCK / L) >= m rows at once
+        const int rows_at_once = SD_BLOCK / L;
+        const int l = tid & (L - 1);
+        for (int e = tid / L; e < m; e += rows_at_once) {
+            const int64_t *cp = p.cptr + (int64_t)hj[e] * nc1 + c;
+            const int64_t q0 = cp[0], q1 = cp[1];
+            const double x = xs[e];
+            for (int64_t q = q0 + l; q < q1; q += L) {
+                const uint2 e2 = p.m_pair[q];
+                const double r = fma(x, (double)__uint_as_float(e2.y), SD_MAGIC) - SD_MAGIC;     // exact product, nearest-even integer
+                atomicAdd(&tab[(int)e2.x - colA], r);
             }
         }
     };
-    // every entry of the user's history rows with column in chunks [ca, cb); `pre` runs before the
-    // first barrier (table set-up that the accumulation must see)
-    auto walk = [&](int ca, int cb, auto &&fn) {
-        if (single) {
-            stage(hb, m1, ca, cb, false);
-            __syncthreads();
-            SP_STAMP(2);
-            sweep(m1, fn);
-        } else {
-            for (int64_t base = hb; base < he; base += SP_HIST) {
-                const int m = (int)min((int64_t)SP_HIST, he - base);
-                __syncthreads();
-                stage(base, m, ca, cb, true);
-                __syncthreads();
-                sweep(m, fn);
+    auto accumulate = [&](int c, int colA) __attribute__((always_inline)) {
+        if (single) accumulate_rows(m1, c, colA);
+        else {
+            for (int64_t base = hb; base < he; base += SD_HIST) {
+                const int m = (int)min((int64_t)SD_HIST, he - base);
+                sd_barrier();
+                stage(base, m);
+                sd_barrier();
+                accumulate_rows(m, c, colA);
             }
         }
     };
-    // x = history weight * 2^shift (exact); the product is exact (24 x 24 bits), rounded to nearest even
-    auto fixed = [&](float wv, double x) -> unsigned long long {
-        return (unsigned long long)__double2ll_rn(x * (double)wv);
-    };
-    // qkey[0, cnt) = the list, qkey[cnt, s_nq) = new keys -> the new list; call after a barrier
-    auto rank_merge = [&]() {
+    // cand[0, cnt) <- the list; cand[cnt, s_nq) = new candidates  ->  the new list.  Call after a barrier.
+    // (check_ex: the new candidates have not been looked up in the user's exclusion row yet -- the entry-driven path
+    // defers that to here, where one lookup per candidate runs for all of them at once)
+    auto rank_merge = [&](bool check_ex) __attribute__((always_inline)) {
         const int total = s_nq, cnt = s_cnt;
-        if (total > cnt && !(SP_DEV && p.dbg == 105)) {
-            for (int e0 = 0; e0 < total; e0 += SP_NG) {
-                const int e = e0 + g;
-                const unsigned long long k = e < total ? qkey[e] : ~0ull;
-                int r = 0;
-                for (int x = l; x < total; x += II_GROUP) r += qkey[x] > k ? 1 : 0;
-                r = sp_row_sum(r);
-                if (l == II_GROUP - 1 && e < total && r < K) top[r] = k;
+        if (tid < cnt) { cand_v[tid] = top_v[tid]; cand_c[tid] = top_c[tid]; }
+        else if (check_ex && tid < total && n_ex != 0) {
+            const int col = cand_c[tid];
+            const int64_t w = ex_lower_bound(col);
+            if (w < n_ex && (ex_lds ? exl[w] : p.ex_idx[eb + w]) == col) { cand_v[tid] = -INFINITY; atomicAdd(&s_dead, 1); }
+        }
+        sd_barrier();
+        for (int e = tid; e < total; e += SD_BLOCK) {
+            const double v = cand_v[e];
+            const int c = cand_c[e];
+            int r = 0;
+            for (int x = 0; x < total; ++x) r += sd_beats(cand_v[x], cand_c[x], v, c) ? 1 : 0;
+            if (r < K && v != -INFINITY) { top_v[r] = v; top_c[r] = c; }
+        }
+        sd_barrier();
+        if (tid == 0) { const int n = min(K, total - s_dead); s_cnt = n; s_nq = n; s_dead = 0; }
+        sd_barrier();
+    };
+    // exact fallback: the K best of (list U the window's candidates) by K rounds of a block-wide argmax over the sums that
+    // are still in the threads' own table slots; the slots are left clean.
+    auto argmax_rounds = [&](int colA, double floor_v, bool strict) __attribute__((always_inline)) {
+        const int cnt = s_cnt;
+        uint32_t taken = 0;                               // bit k: slot k is out of the race; bit 16: my list entry
+        double lv = 0.0; int lc = II_NONE;                // my list entry (threads below cnt)
+        if (tid < cnt) { lv = top_v[tid]; lc = top_c[tid]; } else taken |= 1u << 16;
+        for (int k = 0; k < SD_SPT; ++k) {
+            const double vk = tab[k * SD_BLOCK + tid];
+            if (!(vk != 0.0 && (strict ? vk > floor_v : vk >= floor_v))) taken |= 1u << k;      // (the candidates: all that is left)
+        }
+        sd_barrier();
+        int filled = 0;
+        for (int r = 0; r < K; ++r) {
+            double bv = -INFINITY; int bc = II_NONE;
+            for (int k = 0; k < SD_SPT; ++k) {
+                const int col = colA + k * SD_BLOCK + tid;
+                const double vk = tab[k * SD_BLOCK + tid];
+                if (!(taken & (1u << k)) && (bc == II_NONE || sd_beats(vk, col, bv, bc))) { bv = vk; bc = col; }
+            }
+            if (!(taken & (1u << 16)) && (bc == II_NONE || sd_beats(lv, lc, bv, bc))) { bv = lv; bc = lc; }
+            double wv = bv; int wc = bc;
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) {
+                const double ov = __shfl_xor(wv, off);
+                const int oc = __shfl_xor(wc, off);
+                if (oc != II_NONE && (wc == II_NONE || sd_beats(ov, oc, wv, wc))) { wv = ov; wc = oc; }
+            }
+            if (lane == 0) { wred_v[wave] = wv; wred_c[wave] = wc; }
+            sd_barrier();
+            double gv = wred_v[0]; int gc = wred_c[0];
+            for (int w = 1; w < SD_BLOCK / 64; ++w)
+                if (wred_c[w] != II_NONE && (gc == II_NONE || sd_beats(wred_v[w], wred_c[w], gv, gc))) { gv = wred_v[w]; gc = wred_c[w]; }
+            sd_barrier();
+            if (gc == II_NONE) break;
+            if (tid == 0) { top_v[r] = gv; top_c[r] = gc; }
+            ++filled;
+            if (gc == bc) {                               // mine: retire it
+                if (!(taken & (1u << 16)) && lc == gc) taken |= 1u << 16;
+                else {
+                    for (int k = 0; k < SD_SPT; ++k) if (colA + k * SD_BLOCK + tid == gc) taken |= 1u << k;
+                }
             }
         }
-        __syncthreads();
-        for (int e = tid; e < total; e += SP_BLOCK) qkey[e] = 0ull;
-        if (tid == 0) { const int c = min(K, total); s_cnt = c; s_nq = c; }
-        if (total > SP_SLOTS) __syncthreads();                                  // zeroed words reach into the key area
+        for (int k = 0; k < SD_SPT; ++k) tab[k * SD_BLOCK + tid] = 0.0;
+        sd_barrier();
+        if (tid == 0) { s_cnt = filled; s_nq = filled; }
+        sd_barrier();
     };
 
-    // ---- plan: Tc[c] = entries + exclusions below the start of chunk c
-    __syncthreads();
-    SP_STAMP(0);
-    for (int64_t base = hb; base < he; base += SP_HIST) {
-        const int m = (int)min((int64_t)SP_HIST, he - base);
-        if (base != hb) __syncthreads();
-        for (int e = tid; e < m; e += SP_BLOCK) { hj[e] = p.h_idx[base + e]; hx[e] = p.h_val[base + e]; }
-        __syncthreads();
-        for (int e = g; e < m; e += SP_NG) {
-            const int64_t *cp = p.cptr + (int64_t)hj[e] * nc1;
-            const int64_t r0 = cp[0];
-            for (int c = l + 1; c < nc1; c += II_GROUP) atomicAdd(&Tc[c], (unsigned long long)(cp[c] - r0));
-        }
-    }
-    if (n_ex > 0) {
-        __syncthreads();
-        for (int c = tid + 1; c < nc1; c += SP_BLOCK)
-            Tc[c] += (unsigned long long)ex_lower_bound(c >= (1 << 30) / SP_CHUNK ? 0x7fffffff : c * SP_CHUNK);
-    }
-    __syncthreads();
-    SP_STAMP(1);
-    SP_COUNT(9);
-
-    if (SP_DEV && p.dbg == 101) return;                   // dev ablation 101..105: cumulative early exits, timing only
-    // equal shares: ceil(total / cap) passes of about total / passes entries keep the table load even
-    unsigned long long cap = (unsigned long long)p.sp_cap;
-    {
-        const unsigned long long total = Tc[p.n_chunks], np = (total + cap - 1) / cap;
-        if (np > 1) cap = min(cap, (total + np - 1) / np + cap / 8);
-    }
-    int ca = 0;
-    while (ca < p.n_chunks) {
-        // ---- the pass: chunks [ca, cb)
-        const unsigned long long t0 = Tc[ca];
-        int cb = ca;
-        for (;;) {
-            const int ci = cb + 1 + lane;
-            const bool fits = ci <= p.n_chunks && Tc[min(ci, p.n_chunks)] - t0 <= cap;
-            const int n = __builtin_amdgcn_readfirstlane(__popcll(__ballot(fits)));   // Tc ascends: a prefix of lanes
-            cb += n;
-            if (n < 64) break;
-        }
-        const bool dense = cb == ca;
-        if (dense) cb = ca + 1;
-        if (Tc[cb] == t0) { ca = cb; continue; }          // nothing of this user in these chunks
-        const int colA = ca * SP_CHUNK;
-        const int colB = cb >= (1 << 30) / SP_CHUNK ? 0x7fffffff : cb * SP_CHUNK;
-
-        unsigned long long kreg[SP_REG];
-        if (!dense) {
-            for_exclusions(colA, colB, [&](int col) {
-                const uint32_t key = (uint32_t)(col + 1);
-                int slot = sp_slot(col);
-                const int step = sp_step(col);
-                for (;;) {
-                    const uint32_t old = atomicCAS(&keys[slot], 0u, key | SP_FLAG);
-                    if (old == 0u || (old & ~SP_FLAG) == key) break;
-                    slot = sp_next(slot, step);
-                }
-            });
-            walk(ca, cb, [&](const int (&c)[4], const float (&w)[4], const bool (&ok)[4], double x) {
-                if (SP_DEV && p.dbg == 102) { if (c[0] + c[1] + c[2] + c[3] + __float_as_int(w[0] + w[1] + w[2] + w[3]) == 0x7ffffff1) vals[0] = 1ull; return; }
-                // An LDS atomic costs about the same with one active lane as with 64 (tools/micro/lds_sparse_lanes), so
-                // the probing is arranged for few wave instructions: two queues of two entries per lane, every round
-                // each lane probes once for the entry at the head of either queue (rounds = the longest queue's
-                // probes, not the sum over the entries of the longest probe sequence among the lanes)
-                // every round probes all four entries (finished ones with key 0: CAS(0 -> 0) changes nothing)
-                uint32_t key[4];
-                int slot[4];
-                unsigned long long val[4];
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    key[t] = ok[t] ? (uint32_t)(c[t] + 1) : 0u;
-                    slot[t] = sp_slot(c[t]);
-                    val[t] = fixed(w[t], x);
-                }
-                uint32_t old[4];
-#pragma unroll
-                for (int t = 0; t < 4; ++t) { old[t] = 0u; if (key[t] != 0u) old[t] = atomicCAS(&keys[slot[t]], 0u, key[t]); }
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const bool hit = old[t] == 0u || (old[t] & ~SP_FLAG) == key[t];
-                    if (hit && key[t] != 0u && !(old[t] & SP_FLAG)) atomicAdd(&vals[slot[t]], val[t]);
-                    key[t] = hit ? 0u : key[t];
-                }
-                // the entries whose slot belongs to another column walk on, one entry at a time: only their lanes run
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const int step = sp_step(c[t]);
-                    while (key[t] != 0u) {
-                        slot[t] = sp_next(slot[t], step);
-                        const uint32_t o = atomicCAS(&keys[slot[t]], 0u, key[t]);
-                        if (o == 0u || (o & ~SP_FLAG) == key[t]) {
-                            if (!(o & SP_FLAG)) atomicAdd(&vals[slot[t]], val[t]);
-                            key[t] = 0u;
-                        }
-                    }
-                }
-            });
-            __syncthreads();
-            SP_STAMP(3);
-            SP_COUNT(8);
-            if (SP_DEV && p.dbg == 102) { ca = cb; continue; }
-            if (SP_DEV && p.dbg == 103) {
-                for (int v = 0; v < SP_SPT; ++v) { keys[tid + v * SP_BLOCK] = 0u; vals[tid + v * SP_BLOCK] = 0ull; }
-                ca = cb;
-                continue;
-            }
-            // ---- table slots -> sort keys in registers; the slots are left empty
-            uint32_t kk[SP_SPT];
-            unsigned long long av[SP_SPT];
-#pragma unroll
-            for (int v = 0; v < SP_SPT; ++v) {                                   // exchange: read and clear in one LDS instruction
-                kk[v] = atomicExch(&keys[tid + v * SP_BLOCK], 0u);
-                av[v] = atomicExch(&vals[tid + v * SP_BLOCK], 0ull);
-            }
-#pragma unroll
-            for (int v = 0; v < SP_REG; ++v) {
-                kreg[v] = 0ull;
-                if (v >= SP_SPT) continue;
-                const int col = (int)((kk[v] & ~SP_FLAG) - 1u);
-                float s = (float)ldexp((double)(long long)av[v], -p.fx_shift);  // col_scale is folded into the values
-                const bool live = kk[v] != 0u && !(kk[v] & SP_FLAG);
-                if (live && s == 0.0f && p.pen != nullptr) s *= p.pen[col];     // 0 * inf = NaN like the reference
-                if (s == 0.0f) s = 0.0f;                                        // -0 ranks as +0
-                kreg[v] = live && s == s ? sp_key(s, col) : 0ull;
-            }
-        } else {
-            for_exclusions(colA, colB, [&](int col) { atomicOr(&xbm[(col - colA) >> 5], 1u << (col & 31)); });
-            walk(ca, cb, [&](const int (&c)[4], const float (&w)[4], const bool (&ok)[4], double x) {
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {                                   // an entry past the segment adds 0 / ors 0 at column 0
-                    const int lc = ok[t] ? c[t] - colA : 0;
-                    atomicAdd(&raw[lc], ok[t] ? fixed(w[t], x) : 0ull);
-                    atomicOr(&tbm[lc >> 5], ok[t] ? 1u << (lc & 31) : 0u);
-                }
-            });
-            __syncthreads();
-#pragma unroll
-            for (int v = 0; v < SP_REG; ++v) {
-                kreg[v] = 0ull;
-                if (v >= SP_DPT) continue;
-                const int lc = tid + v * SP_BLOCK;
-                if (lc >= SP_CHUNK) continue;
-                const uint32_t bit = 1u << (lc & 31);
-                if (!(tbm[lc >> 5] & bit)) continue;
-                const long long a = (long long)raw[lc];
-                raw[lc] = 0ull;
-                if (xbm[lc >> 5] & bit) continue;
-                const int col = colA + lc;
-                float s = (float)ldexp((double)a, -p.fx_shift);
-                if (s == 0.0f && p.pen != nullptr) s *= p.pen[col];
-                if (s != s) continue;
-                if (s == 0.0f) s = 0.0f;
-                kreg[v] = sp_key(s, col);
-            }
-        }
-        if (SP_DEV && p.dbg == 104) {
-            if (dense) { __syncthreads(); if (tid < 2 * (SP_CHUNK / 32)) tbm[tid] = 0u; }
-            unsigned long long z = 0;
-            for (int v = 0; v < SP_REG; ++v) z ^= kreg[v];
-            if (z == 0x1234567ull) top[0] = z;
-            ca = cb;
-            continue;
-        }
-        // ---- bound: the list's K-th key, or (list not full) the best wave's K-th best thread maximum
+    // ---- after the window's entries are in the table: exclusions, scan, candidates.  The scan keeps NOTHING in registers
+    // across the window: a thread reads its 16 sums for a running maximum, ONE compare against the list's K-th sum says
+    // whether it holds a candidate at all (after the first windows almost never), and it clears its slots; only a thread
+    // with candidates reads its slots again.  (Swapping the slots for zero into 16 register pairs cost 32 VGPRs, which
+    // evicted the prefetched entries of the next window: the compiler drained every load in flight at that point.)
+    auto scan_and_select = [&](int colA) __attribute__((always_inline)) {
+        poison(colA, colA + SP_CHUNK);
+        sd_barrier();
         const int cnt = s_cnt;
-        if (cnt < K) {
-            uint32_t lm = 0u;
-#pragma unroll
-            for (int v = 0; v < SP_REG; ++v) lm = max(lm, (uint32_t)(kreg[v] >> 32));
-            uint32_t vk = 0u;
+        double floor_v;                                   // candidates: sums strictly above (list full) / at or above (short list)
+        bool strict;
+        if (cnt == K) {
+            floor_v = top_v[K - 1]; strict = true;
+        } else {
+            // short list: the wave's K-th best thread maximum is a lower bound of the window's K-th best sum
+            double lm = -INFINITY;
+            for (int k = 0; k < SD_SPT; ++k) { const double vk = tab[k * SD_BLOCK + tid]; lm = (vk != 0.0 && vk > SD_LIVE) ? fmax(lm, vk) : lm; }
+            double vk = -INFINITY;
             for (int r = 0; r < K; ++r) {
-                vk = sp_wave_max(lm);
-                if (vk == 0u) break;
+                vk = sd_wave_max(lm);
+                if (vk == -INFINITY) break;
                 const unsigned long long b = __ballot(lm == vk);
-                if (lane == __ffsll((long long)b) - 1) lm = 0u;
+                if (lane == __ffsll((long long)b) - 1) lm = -INFINITY;
             }
-            if (lane == 0) wred[wave] = vk;
-        }
-        __syncthreads();                                   // every slot is in registers: raw becomes qkey
-        SP_STAMP(4);
-        unsigned long long tau;
-        if (cnt < K) {
-            uint32_t th = 0u;
+            if (lane == 0) wred_v[wave] = vk;
+            sd_barrier();
+            floor_v = wred_v[0];
 #pragma unroll
-            for (int w = 0; w < SP_BLOCK / 64; ++w) th = max(th, wred[w]);
-            tau = th ? ((unsigned long long)th << 32) - 1ull : 0ull;
-        } else tau = top[K - 1];
-        if (dense && tid < 2 * (SP_CHUNK / 32)) tbm[tid] = 0u;                  // tbm and xbm are contiguous
-        if (tid < cnt) qkey[tid] = top[tid];
-#pragma unroll
-        for (int v = 0; v < SP_REG; ++v) {
-            const bool q = kreg[v] > tau;
-            if (__any(q)) { if (q) qkey[atomicAdd(&s_nq, 1)] = kreg[v]; }
+            for (int w = 1; w < SD_BLOCK / 64; ++w) floor_v = fmax(floor_v, wred_v[w]);
+            floor_v = fmax(floor_v, SD_LIVE);
+            strict = false;
         }
-        __syncthreads();
-        SP_STAMP(5);
-        rank_merge();
-        ca = cb;
-        SP_STAMP(6);
-    }
-    __syncthreads();
-    if (SP_DEV && p.dbg >= 101) return;
+        double mx = tab[tid];
+#pragma unroll
+        for (int k = 1; k < SD_SPT; ++k) mx = fmax(mx, tab[k * SD_BLOCK + tid]);
+        uint32_t mine = 0;                                // my slots that hold a candidate: cleared after the ranking
+        if (strict ? mx > floor_v : mx >= floor_v) {
+            for (int k = 0; k < SD_SPT; ++k) {
+                const double vk = tab[k * SD_BLOCK + tid];
+                if (vk != 0.0 && (strict ? vk > floor_v : vk >= floor_v)) {
+                    mine |= 1u << k;
+                    const int pos = atomicAdd(&s_nq, 1);
+                    if (pos < cap) { cand_v[pos] = vk; cand_c[pos] = colA + k * SD_BLOCK + tid; }
+                }
+            }
+        }
+        if (__any(mine != 0u)) {
+#pragma unroll
+            for (int k = 0; k < SD_SPT; ++k) if (!(mine & (1u << k))) tab[k * SD_BLOCK + tid] = 0.0;
+        } else {                                          // the common case, branch-free: nobody in the wave holds a candidate
+#pragma unroll
+            for (int k = 0; k < SD_SPT; ++k) tab[k * SD_BLOCK + tid] = 0.0;
+        }
+        sd_barrier();                                  // appends done; every slot without a candidate is clean
+        const int total = s_nq;
+        if (total > cap) argmax_rounds(colA, floor_v, strict);      // more candidates than the buffer holds (mass ties): exact rounds
+        else if (total > cnt) {
+            for (int k = 0; k < SD_SPT; ++k) if (mine & (1u << k)) tab[k * SD_BLOCK + tid] = 0.0;
+            rank_merge(false);
+        }
+    };
 
-    // ---- untouched columns (score 0 * col_scale): only when they can still enter the list
-    {
-        uint32_t *const zbm = reinterpret_cast<uint32_t *>(raw + SP_RAW - SP_CHUNK / 64);
-        int found = 0;
-        for (int chunk = 0; chunk < p.n_chunks && found < K; ++chunk) {
-            const int c0 = chunk * SP_CHUNK;
-            const int cnt = s_cnt;
-            const unsigned long long tau = cnt == K ? top[K - 1] : 0ull;
-            if (cnt == K && !(sp_key(0.0f, c0) > tau)) break;
-            walk(chunk, chunk + 1, [&](const int (&c)[4], const float (&)[4], const bool (&ok)[4], double) {
+    // ---------------------------------------------------------------- main sweep
+    if (single) {
+        // The common case (history <= SD_HIST rows): a thread keeps ONE row for the whole sweep, and the loop is software
+        // pipelined -- the entries of window c + 1 (SD_PRE per lane) and the row's entry position two windows ahead are
+        // requested at the top of window c, so that no global round trip sits between two barriers (without this the
+        // kernel spends ~4 us per window waiting on two dependent loads: 125 ms per 1 M users at C5).
+        int L = SD_BLOCK;
+        while (L > 1 && SD_BLOCK / L < m1) L >>= 1;
+        const int e = tid / L, l = tid & (L - 1);
+        const bool has_row = e < m1;
+        const int64_t *cpb = p.cptr + (int64_t)(has_row ? hj[e] : 0) * nc1;
+        const double x = has_row ? xs[e] : 0.0;
+        // entry positions as 32-bit offsets from the row's first entry (a row has fewer than 2^31 entries); IDX32: the whole
+        // matrix has fewer than 2^30 entries, so a 32-bit index addresses any of them from the (uniform) array base
+        const int64_t row0q = has_row ? cpb[0] : 0;
+        // the entries as interleaved (column, value) pairs (m_pair, built at set time): ONE 8-byte load per entry, and a row's
+        // segment of a window -- ~8 entries -- is 64 contiguous bytes.  With separate index / value arrays each segment
+        // touched two cache lines for 32 useful bytes each, and the L2 -> L1 line traffic (4 x the useful bytes per array,
+        // fetched again by the next window) set the pace: 105 ms per 1 M users at C5 whatever the instruction count.
+        const uint2 *const rp = p.m_pair + (IDX32 ? 0 : row0q);
+        const uint32_t base32 = IDX32 ? (uint32_t)row0q : 0u;
+        struct Pre { uint2 ent[SD_PRE]; int first, end; };
+        // Every load below is UNCONDITIONAL (out-of-range lanes read a clamped, valid address and are masked at use) and
+        // nothing computed from a loaded value is touched before the next window: the compiler can then count the loads
+        // in flight (s_waitcnt vmcnt(n)) instead of draining them all, which is what makes the prefetch overlap at all.
+        auto issue = [&](Pre &s, int qa, int qb) __attribute__((always_inline)) {
+            const int last = max(qb - 1, 0);
 #pragma unroll
-                for (int t = 0; t < 4; ++t)
-                    if (ok[t]) { const int lc = c[t] - c0; atomicOr(&zbm[lc >> 5], 1u << (lc & 31)); }
-            });
-            __syncthreads();
+            for (int t = 0; t < SD_PRE; ++t) s.ent[t] = rp[base32 + (uint32_t)min(qa + l + t * L, last)];
+            s.first = qa + l;
+            s.end = qb;
+        };
+        // branch-free: an entry past the segment adds 0.0 to one of the lane's own slots
+        auto consume = [&](const Pre &s, int colA) __attribute__((always_inline)) {
+#pragma unroll
+            for (int t = 0; t < SD_PRE; ++t) {
+                const bool ok = s.first + t * L < s.end;
+                const double r = fma(x, (double)__uint_as_float(s.ent[t].y), SD_MAGIC) - SD_MAGIC;
+                atomicAdd(&tab[ok ? (int)s.ent[t].x - colA : SP_CHUNK + lane], ok ? r : 0.0);
+            }
+            for (int q = s.first + SD_PRE * L; q < s.end; q += L) {        // segments longer than the prefetch (rare)
+                const uint2 e2 = rp[base32 + (uint32_t)q];
+                atomicAdd(&tab[(int)e2.x - colA], fma(x, (double)__uint_as_float(e2.y), SD_MAGIC) - SD_MAGIC);
+            }
+        };
+        // (only the LOW 32 bits of an entry position are loaded: the difference to the row's first entry fits, and a 64-bit
+        // load whose upper half is dead lets the register allocator reuse that half while the load is in flight -- which
+        // costs a full drain of the loads at the next write to it)
+        auto pos_lo = [&](int k) __attribute__((always_inline)) { return reinterpret_cast<const uint32_t *>(cpb + k)[0]; };
+        const uint32_t row0lo = (uint32_t)row0q;
+        int b1 = has_row ? (int)(pos_lo(1) - row0lo) : 0;                         // my row's offset at the start of window c + 1
+        uint32_t b2raw = pos_lo(min(2, p.n_chunks));                              // ... of window c + 2, as loaded (converted when used)
+        Pre A, B;
+        issue(A, 0, b1);
+        // ---- the window's selection, ENTRY-driven: after the barrier every lane swaps the slot of each of its entries for
+        // zero.  The first lane to arrive at a column takes its (complete) sum, the others get 0: every touched slot is
+        // read once, cleared, and owned by exactly one lane -- no scan of the 4096 slots, no poison for the exclusions (a
+        // candidate is looked up in the user's exclusion row instead: after the first windows candidates are rare).
+        // Lanes without an entry swap a private dummy slot behind the table.
+        int cnt_r = 0, nq_prev = 0;                       // register copies of s_cnt / s_nq at the window's start / the list's K-th sum
+        double tau = 0.0;
+        auto excluded = [&](int col) __attribute__((always_inline)) -> bool {
+            if (n_ex == 0) return false;
+            const int64_t w = ex_lower_bound(col);
+            return w < n_ex && (ex_lds ? exl[w] : p.ex_idx[eb + w]) == col;
+        };
+        auto append = [&](double v, int col) __attribute__((always_inline)) {
+            const int pos = atomicAdd(&s_nq, 1);
+            if (pos < cap) { cand_v[pos] = v; cand_c[pos] = col; }
+        };
+        auto claim = [&](int slot) __attribute__((always_inline)) -> double {
+            return __longlong_as_double((long long)atomicExch(reinterpret_cast<unsigned long long *>(&tab[slot]), 0ull));
+        };
+        auto select_claimed = [&](const Pre &s, int c) __attribute__((always_inline)) {
+            const int colA = c * SP_CHUNK;
+            const bool full = cnt_r == K;
+            double v[SD_PRE];
+#pragma unroll
+            for (int t = 0; t < SD_PRE; ++t) {
+                const bool ok = s.first + t * L < s.end;
+                v[t] = claim(ok ? (int)s.ent[t].x - colA : SP_CHUNK + lane);
+            }
+            for (int q = s.first + SD_PRE * L; q < s.end; q += L) {        // segments longer than the prefetch (rare)
+                const int col = (int)rp[base32 + (uint32_t)q].x;
+                const double vv = claim(col - colA);
+                if (vv != 0.0 && (!full || vv > tau)) append(vv, col);      // (exclusions: looked up at the merge)
+            }
+            if (full) {
+#pragma unroll
+                for (int t = 0; t < SD_PRE; ++t)
+                    if (v[t] != 0.0 && v[t] > tau) append(v[t], (int)s.ent[t].x);     // (exclusions: looked up at the merge)
+            } else {
+                // short list: a lower bound of the window's K-th best sum.  Keys = the high words of the lanes' best sums,
+                // order-preserving (0 = no sum); a bit-by-bit search (ballot + popcount, no cross-lane data movement)
+                // finds the top SD_FLOOR_BITS bits of the wave's K-th largest key: at least K lanes -- K distinct columns,
+                // a column's sum is held by one lane only -- are at or above it.  Excluded columns are looked up first
+                // (they must not lift the bound).
+                uint32_t kmax = 0, key[SD_PRE];
+#pragma unroll
+                for (int t = 0; t < SD_PRE; ++t) {
+                    if (v[t] != 0.0 && excluded((int)s.ent[t].x)) v[t] = 0.0;
+                    const uint32_t hi = (uint32_t)__double2hiint(v[t]);
+                    key[t] = v[t] != 0.0 ? (hi ^ ((uint32_t)((int32_t)hi >> 31) | 0x80000000u)) : 0u;
+                    kmax = max(kmax, key[t]);
+                }
+                uint32_t fl = 0;
+#pragma unroll
+                for (int b = 31; b > 31 - SD_FLOOR_BITS; --b) {
+                    const uint32_t trial = fl | (1u << b);
+                    if (__popcll(__ballot(kmax >= trial)) >= K) fl = trial;
+                }
+                if (lane == 0) wred_n[wave] = fl;
+                sd_barrier();
+                uint32_t floor_k = wred_n[0];
+#pragma unroll
+                for (int w = 1; w < SD_BLOCK / 64; ++w) floor_k = max(floor_k, wred_n[w]);
+                floor_k = max(floor_k, 1u);
+#pragma unroll
+                for (int t = 0; t < SD_PRE; ++t)
+                    if (key[t] >= floor_k) append(v[t], (int)s.ent[t].x);
+            }
+            sd_barrier();                                 // appends done, every touched slot is clean
+            const int total = s_nq;
+            if (total > cap) {
+                // more candidates than the buffer holds (mass ties): the table is clean, so -- after the candidates of the
+                // earlier windows are merged -- the window is accumulated again and ranked by the scanning path (exact
+                // argmax rounds)
+                sd_barrier();                             // (everybody has read s_nq)
+                if (tid == 0) s_nq = nq_prev;
+                sd_barrier();
+                if (nq_prev > cnt_r) rank_merge(true);
+                accumulate_rows(m1, c, colA);
+                scan_and_select(colA);
+                cnt_r = s_cnt; tau = top_v[K - 1]; nq_prev = cnt_r;
+            } else if (total > cnt_r && (!full || total - cnt_r >= SD_LAZY || total + SD_LAZY > cap)) {
+                // LAZY merge: while the list is full, new candidates wait behind it (the stale K-th sum only admits a few
+                // more) until SD_LAZY of them are pending: ~4 merges per user instead of one in every second window
+                rank_merge(true);
+                cnt_r = s_cnt; tau = top_v[K - 1]; nq_prev = cnt_r;
+            } else nq_prev = total;
+        };
+        auto window = [&](int c, const Pre &cur, Pre &nxt) __attribute__((always_inline)) {
+            const int b2 = has_row ? (int)(b2raw - row0lo) : 0;     // requested a whole window ago
+            issue(nxt, b1, b2);                                     // window c + 1 (an empty range past the last window)
+            b2raw = pos_lo(min(c + 3, p.n_chunks));
+            consume(cur, c * SP_CHUNK);
+            b1 = b2;
+            sd_barrier();                                           // the window's sums are complete
+            select_claimed(cur, c);
+        };
+        for (int c = 0; c < p.n_chunks; c += 2) {
+            window(c, A, B);
+            if (c + 1 < p.n_chunks) window(c + 1, B, A);
+        }
+        if (nq_prev > cnt_r) rank_merge(true);                      // the candidates still pending
+    } else {
+        for (int c = 0; c < p.n_chunks; ++c) {
+            accumulate(c, c * SP_CHUNK);
+            scan_and_select(c * SP_CHUNK);
+        }
+    }
+
+    // ---------------------------------------------------------------- zero sums (score 0 * col_scale): only when they can still rank
+    {
+        int found = 0;
+        for (int c = 0; c < p.n_chunks && found < K; ++c) {
+            const int colA = c * SP_CHUNK;
+            const int cnt = s_cnt;
+            const double tv = cnt == K ? top_v[K - 1] : 0.0;
+            const int tc = cnt == K ? top_c[K - 1] : II_NONE;
+            if (cnt == K && !sd_beats(0.0, colA, tv, tc)) break;      // not even the window's first column would rank
+            sd_barrier();
+            accumulate(c, colA);
+            poison(colA, colA + SP_CHUNK);
+            sd_barrier();
+            // contiguous slots per thread here: zero columns are taken in COLUMN order
             int mine = 0;
             uint32_t okbits = 0;
-            for (int v = 0; v < SP_ZC; ++v) {
-                const int lc = SP_ZC * tid + v;
-                const int col = c0 + lc;
-                bool ok = lc < SP_CHUNK && col < p.n_items && !((zbm[min(lc, SP_CHUNK - 1) >> 5] >> (lc & 31)) & 1u);
+#pragma unroll
+            for (int k = 0; k < SD_SPT; ++k) {
+                const int lc = SD_SPT * tid + k;
+                const int col = colA + lc;
+                bool ok = tab[lc] == 0.0 && col < p.n_items;
                 if (ok && p.pen != nullptr) { const float z = 0.0f * p.pen[col]; ok = z == z; }
-                if (ok) ok = sp_key(0.0f, col) > tau && !excluded(col);
-                if (ok) { okbits |= 1u << v; ++mine; }
+                if (ok) ok = cnt < K || sd_beats(0.0, col, tv, tc);
+                if (ok) { okbits |= 1u << k; ++mine; }
             }
             int incl = mine;                                                  // block exclusive prefix of `mine`
 #pragma unroll
             for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(incl, off); if (lane >= off) incl += t; }
-            if (lane == 63) wred[wave] = (uint32_t)incl;
-            __syncthreads();
+            if (lane == 63) wred_n[wave] = (uint32_t)incl;
+            sd_barrier();
             int before = incl - mine, all = 0;
-            for (int w = 0; w < SP_BLOCK / 64; ++w) { if (w < wave) before += (int)wred[w]; all += (int)wred[w]; }
-            if (tid < SP_CHUNK / 32) zbm[tid] = 0u;
-            if (tid < cnt) qkey[tid] = top[tid];
+            for (int w = 0; w < SD_BLOCK / 64; ++w) { if (w < wave) before += (int)wred_n[w]; all += (int)wred_n[w]; }
+#pragma unroll
+            for (int k = 0; k < SD_SPT; ++k) tab[SD_SPT * tid + k] = 0.0;    // my slots: clean for the next window
             before += found;
-            for (int v = 0; v < SP_ZC && before < K; ++v)
-                if (okbits & (1u << v)) { qkey[atomicAdd(&s_nq, 1)] = sp_key(0.0f, c0 + SP_ZC * tid + v); ++before; }
+            // at most K zero columns rank in all (they tie: column order), so at most K - found enter here
+            for (int k = 0; k < SD_SPT && before < K; ++k)
+                if (okbits & (1u << k)) {
+                    const int pos = atomicAdd(&s_nq, 1);
+                    cand_v[pos] = 0.0; cand_c[pos] = colA + SD_SPT * tid + k;     // cnt + (K - found) <= 2 K <= SD_CAND
+                    ++before;
+                }
             found += all;
-            __syncthreads();
-            rank_merge();
-            __syncthreads();
+            sd_barrier();
+            if (s_nq > cnt) rank_merge(false);
         }
     }
+    sd_barrier();
 
     const int cnt = s_cnt;
     if (tid < K) {
-        const unsigned long long k = top[tid];
-        out_ids[i * K + tid] = tid < cnt ? (int32_t)(~(uint32_t)k) : -1;
-        out_scores[i * K + tid] = tid < cnt ? sp_key_float((uint32_t)(k >> 32)) : -INFINITY;
+        int32_t id = -1;
+        float sc = -INFINITY;
+        if (tid < cnt) {
+            id = top_c[tid];
+            sc = (float)ldexp(top_v[tid], -p.fx_shift);                       // the exact sum scaled back, ONE rounding to fp32
+            if (sc == 0.0f) sc = 0.0f;                                        // (a zero sum is +0: 0 * col_scale was finite)
+        }
+        out_ids[i * K + tid] = id;
+        out_scores[i * K + tid] = sc;
     }
-    SP_STAMP(7);
 }
 
-// dev (make ABLATE=1): the phase counters, cleared by the read; -1 in a product build
 int item_sparse_read_phases(unsigned long long *out16)
 {
-#ifdef IFR_ABLATE
-    unsigned long long z[16] = {0};
-    if (hipDeviceSynchronize() != hipSuccess || hipMemcpyFromSymbol(out16, HIP_SYMBOL(sp_phase), sizeof(z)) != hipSuccess ||
-        hipMemcpyToSymbol(HIP_SYMBOL(sp_phase), z, sizeof(z)) != hipSuccess) return -3;
-    return 0;
-#else
     (void)out16;
     return -1;
-#endif
 }
 
 int launch_item_sparse_topk(const ItemItemParams &p, int32_t *out_ids, float *out_scores, hipStream_t stream)
 {
-    if (p.n <= 0 || p.n > (int64_t)0xffffffffu / SP_BLOCK || p.K < 1 || p.K > 32) return -1;
-    if (p.n_chunks < 1 || p.n_chunks > SP_MAXCH || p.sp_cap < 1 || p.sp_cap > SP_CAP) return -1;
-    static bool attr_done[64] = {false};                 // more than 64 KB of LDS needs the opt-in, once per device
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return -3;
-    bool &attr_set = attr_done[dev];
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(item_sparse_topk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)SP_LDS_BYTES) != hipSuccess) return -3;
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(item_sparse_topk_kernel, dim3((unsigned)p.n), dim3(SP_BLOCK), SP_LDS_BYTES, stream, p, out_ids, out_scores);
+    if (p.n <= 0 || p.n > (int64_t)0xffffffffu / SD_BLOCK || p.K < 1 || p.K > SD_MAXK) return -1;
+    if (p.n_chunks < 1 || p.sp_cap < 2 * SD_MAXK || p.sp_cap > SD_CAND) return -1;
+    // fewer than 2^30 entries (+ the over-read pad): 32-bit entry indices from the array bases (fewer address instructions)
+    if (p.m_nnz + II_CSR_PAD < ((int64_t)1 << 30))
+        hipLaunchKernelGGL(item_sparse_topk_kernel<true>, dim3((unsigned)p.n), dim3(SD_BLOCK), 0, stream, p, out_ids, out_scores);
+    else
+        hipLaunchKernelGGL(item_sparse_topk_kernel<false>, dim3((unsigned)p.n), dim3(SD_BLOCK), 0, stream, p, out_ids, out_scores);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
-int item_sparse_pass_capacity() { return SP_CAP; }
-int item_sparse_max_chunks() { return SP_MAXCH; }
+int item_sparse_pass_capacity() { return SD_CAND; }
+int item_sparse_min_capacity() { return 2 * SD_MAXK; }
+int item_sparse_max_chunks() { return 1 << 20; }
 
 // fp64 option: one wave per user ranks the n_lists * KL partial entries by counting (score descending on the DOUBLES,
 // item index ascending) and writes the first K; the scores leave as fp32 (rounded once, after the ranking).
@@ -997,6 +994,11 @@ int launch_item_item(const ItemItemParams &p, bool sparse, bool topk, hipStream_
     // HIP limits grid.x * block.x to 32 bits and grid.y to 65535
     if (p.n <= 0 || p.n_chunks <= 0 || p.n > (int64_t)0xffffffffu / II_BLOCK || p.n_chunks > 65535) return -1;
     const dim3 g((unsigned)p.n, (unsigned)p.n_chunks), b(II_BLOCK);
+    if (sparse && p.out64 != nullptr) {                  // fp64 rows of a CSR matrix
+        if (topk) return -1;
+        hipLaunchKernelGGL((item_item_kernel<II_SPARSE_PASSES, true, false>), g, b, 0, stream, p);
+        return hipGetLastError() == hipSuccess ? 0 : -3;
+    }
     if (p.M64 != nullptr) {
         if (sparse) return -1;
         if (topk) hipLaunchKernelGGL((item_item_kernel<II_F64_PASSES, false, true, true>), g, b, 0, stream, p);
@@ -1090,6 +1092,20 @@ __global__ void row_l1_max_kernel(const int64_t *ptr, const float *val, int64_t 
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, off));
     if ((threadIdx.x & 63) == 0) atomicMax(out, m);
+}
+
+// (column, value) pairs of a CSR matrix: what item_sparse_topk_kernel streams
+__global__ void interleave_csr_kernel(const int32_t *idx, const float *val, int64_t n, uint2 *pair)
+{
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (int64_t)gridDim.x * blockDim.x)
+        pair[q] = make_uint2((uint32_t)idx[q], __float_as_uint(val[q]));
+}
+int launch_interleave_csr(const int32_t *idx, const float *val, int64_t n, uint2 *pair, hipStream_t s)
+{
+    const int64_t blocks = (n + 255) / 256;
+    const unsigned grid = (unsigned)(blocks < 1 ? 1 : (blocks > 16384 ? 16384 : blocks));
+    hipLaunchKernelGGL(interleave_csr_kernel, dim3(grid), dim3(256), 0, s, idx, val, n, pair);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
 int launch_validate_csr(const int64_t *ptr, const int32_t *idx, int64_t n_rows, int n_cols, int need_sorted, int *bad,

@@ -437,9 +437,11 @@ class HipScorer:
         self.catalogue_items = max(n_total, self.n_items)
 
     def rows_are_f64(self):
-        """True for an item matrix installed with precision="f64": its native score rows are float64, and everything
-        that ranks them orders the float64 values (the reference's precision for EASE, recom_ease.py:123-124)."""
-        return self.item_model == "dense" and getattr(self, "item_precision", "f32") == "f64"
+        """True for a dense item matrix installed with precision="f64" and for every CSR item matrix (whose fixed-point
+        sums are exact in float64): the native score rows are float64, and everything that ranks them orders the
+        float64 values, like the reference does with its float64 scores (recom_ease.py:123-124,
+        graph_recommender.py:104-117) -- and like the fused top-K kernels of these models."""
+        return (self.item_model == "dense" and getattr(self, "item_precision", "f32") == "f64") or self.item_model == "csr"
 
     def max_dense_metric_pos(self):
         """Positives per row ifr_eval_dense_metrics[_f64] takes (float64 rows: 128-bit keys, half as many fit the LDS)."""
@@ -489,7 +491,8 @@ class HipScorer:
         return out
 
     def score_dense_f64(self, user_ids, out=None):
-        """float64 score rows [n, n_items] of an item matrix installed with precision="f64"."""
+        """float64 score rows [n, n_items] of a dense item matrix installed with precision="f64", or of a CSR item matrix
+        (its exact fixed-point sums scaled back)."""
         torch = _torch()
         u = self._dev_users(user_ids)
         n = u.numel()

@@ -450,7 +450,7 @@ class ItemItemScoringMixin(HipScoringMixin):
         return int(user_idx) if self.knows_user(user_idx) else -1
 
     def _hip_score_row(self, eng, row):
-        if getattr(self, "precision", "f32") == "f64" and eng.item_model == "dense":
+        if eng.rows_are_f64():            # float64 dense matrix, or a CSR matrix (exact sums): the scores that are ranked
             return eng.score_dense_f64(np.asarray([row], np.int32))[0][: eng.n_items]
         return eng.score_dense(np.asarray([row], np.int32))[0]
 

@@ -54,9 +54,10 @@ def factor_model(rng, n_users, n_items, k, has_bias):
     return U, V, ubase, ibase
 
 
-def make(name, n_users=None, n_items=None, seed=None):
-    """Workload dict for a named config (optionally scaled down for parity tests)."""
-    nu, ni, k, mean, sd, bias = CONFIGS[name]
+def make(name, n_users=None, n_items=None, seed=None, k=None):
+    """Workload dict for a named config (optionally scaled down for parity tests; k: another factor dimension)."""
+    nu, ni, k0, mean, sd, bias = CONFIGS[name]
+    k = k0 if k is None else int(k)
     nu = nu if n_users is None else n_users
     ni = ni if n_items is None else n_items
     rng = np.random.default_rng(sd if seed is None else seed)

@@ -96,17 +96,18 @@ def test_csr_topk_bit_exact_vs_oracle(torch, n_items, row_nnz, K, pen):
                                                                    w["col_scale"])
 
 
-@pytest.mark.parametrize("pass_entries", [0, 700, 40])
+@pytest.mark.parametrize("pass_entries", [0, 64])
 def test_csr_topk_pass_shapes(torch, pass_entries):
-    """The CSR top-K kernel under every pass shape: one hash pass, many hash passes, single-chunk dense passes
-    (pass_entries below a chunk's entries), histories longer than a staging round (128 rows), exclusion rows beyond
-    the LDS copy (256 entries), negative values (zero-score columns enter the list) and users without history."""
+    """The CSR top-K kernel over its paths: candidates ranked by counting and -- candidate buffer cut to 64 entries,
+    which the first windows of these users overflow -- by the exact block-wide argmax rounds; histories longer than a
+    staging round (128 rows), exclusion rows beyond the LDS copy (256 entries), negative values (zero-sum columns
+    enter the list) and users without history."""
     w = _workload(77, 160, 9000, 120, row_nnz=60, weights="ratings", pen=True)
     assert np.diff(w["h_ptr"]).max() > 256                                  # staging rounds and a global exclusion row
     w["csr"].data[::3] *= -1.0
     sc = _scorer(w)
     if pass_entries:
-        sc.set_option("csr_pass_entries", pass_entries)
+        sc.set_option("csr_cand_cap", pass_entries)
     users = np.r_[np.arange(w["n_users"]), [w["n_users"] + 5]].astype(np.int32)
     for K in (10, 32):
         ids, scores = sc.rank_topk(users, K)
@@ -117,7 +118,7 @@ def test_csr_topk_pass_shapes(torch, pass_entries):
     w["csr"].data[:] = -np.abs(w["csr"].data)
     sc = _scorer(w)
     if pass_entries:
-        sc.set_option("csr_pass_entries", pass_entries)
+        sc.set_option("csr_cand_cap", pass_entries)
     ids, scores = sc.rank_topk(users, 10)
     o_ids, o_sc, _, _ = _oracle(w, sc, users, [10], 10)
     np.testing.assert_array_equal(ids.cpu().numpy(), o_ids)

@@ -52,7 +52,7 @@ for case in range(cases):
     sc.set_exclusion_csr(e_ptr, e_idx)
     sc.set_truth_csr(np.zeros(n_users + 1, np.int64), np.zeros(0, np.int32))
     if form == "csr" and rng.integers(2):
-        sc.set_option("csr_pass_entries", int(rng.choice([40, 700, 2000])))
+        sc.set_option("csr_cand_cap", int(rng.choice([64, 100, 256])))
     t = time.perf_counter()
     ids, scores = sc.rank_topk(users, K)
     ids, scores = ids.cpu().numpy(), scores.cpu().numpy()
