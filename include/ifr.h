@@ -156,6 +156,33 @@ int ifr_set_exclusion_csr(ifr_handle h, const int64_t *indptr, const int32_t *in
 int ifr_set_truth_csr(ifr_handle h, const int64_t *indptr, const int32_t *indices,
                       int64_t n_rows, int64_t nnz);
 
+/* One split as the reference's Dataset.csr_matrix holds it (cornac/data/dataset.py:229-238), in DEVICE memory. */
+typedef struct ifr_csr_split {
+    const int64_t *indptr;   /* dev [n_rows + 1]; NULL = no such split                                   */
+    const int32_t *indices;  /* dev [nnz]: columns strictly ascending inside a row (canonical CSR)        */
+    const void *ratings;     /* dev [nnz]: float64 (ratings_f64 != 0, the reference's dtype) or float32   */
+    int64_t n_rows;
+} ifr_csr_split;
+
+/* The candidate-set builder of ranking_eval (cornac/eval_methods/base_method.py:246-283, SURVEY.md Appendix B rules
+ * 1-3) on the device: from the raw train / validation (may be NULL) / test rating matrices, for the users
+ * [row0, row0 + n_rows) (output row i = user row0 + i; rows past a split's n_rows are empty, :266-270):
+ *     truth[u]     = test items rated >= rating_threshold, item < n_items                       (gt_pos, :257-263)
+ *     exclusion[u] = (train U validation items rated >= rating_threshold, < n_items) - truth[u] (:246-251, 265-283)
+ *     has_pos[u]   = u has a test item rated >= rating_threshold BEFORE the clip to n_items     (:257-259: evaluated)
+ * and installs both CSRs in the handle exactly as ifr_set_truth_csr / ifr_set_exclusion_csr would (rows ascending).
+ * One wave per user row, two sweeps (count, prefix sums, fill) + a merge of the train / validation runs: index work,
+ * bound by the HBM read of the raw rows.  has_pos: "any" pointer to n_rows bytes, or NULL; the three counts: host,
+ * or NULL.  Needs the model set (the exclusion encoding depends on the model's item count). */
+int ifr_build_eval_csrs(ifr_handle h, const ifr_csr_split *train, const ifr_csr_split *val, const ifr_csr_split *test,
+                        int ratings_f64, double rating_threshold, int64_t n_items, int64_t row0, int64_t n_rows,
+                        uint8_t *has_pos, int64_t *truth_nnz, int64_t *excl_nnz, int *max_truth_row);
+
+/* Reads back the truth (which = 0) or exclusion (which = 1) CSR the handle holds -- however it was set -- into "any"
+ * buffers of n_rows + 1 / nnz entries; with NULL buffers only the sizes are returned.  (Host consumers: the
+ * reference's per-user caches, tests.)  No reference counterpart. */
+int ifr_read_eval_csr(ifr_handle h, int which, int64_t *indptr, int32_t *indices, int64_t *n_rows, int64_t *nnz);
+
 /* Fused scoring + exclusion + top-K selection for a batch of users.  Replaces the head of
  * Recommender.rank (cornac/models/recommender.py:624-652: score, candidate gather,
  * argsort/argpartition) for every listed user at once.  Order: score descending, item index

@@ -16,6 +16,12 @@ c_f32p = ctypes.POINTER(ctypes.c_float)
 c_f64p = ctypes.POINTER(ctypes.c_double)
 vp = ctypes.c_void_p
 
+
+class CsrSplit(ctypes.Structure):
+    """ifr_csr_split (include/ifr.h): one rating split in device memory."""
+    _fields_ = [("indptr", vp), ("indices", vp), ("ratings", vp), ("n_rows", ctypes.c_int64)]
+
+
 # name -> (restype, argtypes); one row per declaration in include/ifr.h
 SIGNATURES = {
     "ifr_version": (ctypes.c_char_p, []),
@@ -44,6 +50,10 @@ SIGNATURES = {
     "ifr_item_fixed_point_shift": (ctypes.c_int, [vp, ctypes.POINTER(ctypes.c_int)]),
     "ifr_set_exclusion_csr": (ctypes.c_int, [vp, vp, vp, ctypes.c_int64, ctypes.c_int64]),
     "ifr_set_truth_csr": (ctypes.c_int, [vp, vp, vp, ctypes.c_int64, ctypes.c_int64]),
+    "ifr_build_eval_csrs": (ctypes.c_int, [vp, ctypes.POINTER(CsrSplit), ctypes.POINTER(CsrSplit), ctypes.POINTER(CsrSplit),
+                                           ctypes.c_int, ctypes.c_double, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
+                                           vp, c_i64p, c_i64p, ctypes.POINTER(ctypes.c_int)]),
+    "ifr_read_eval_csr": (ctypes.c_int, [vp, ctypes.c_int, vp, vp, c_i64p, c_i64p]),
     "ifr_rank_topk": (ctypes.c_int, [vp, vp, ctypes.c_int64, ctypes.c_int, vp, vp, vp]),
     "ifr_rank_topk_noalloc": (ctypes.c_int, [vp, vp, ctypes.c_int64, ctypes.c_int, vp, vp, vp]),
     "ifr_rank_topk_dense": (ctypes.c_int, [vp, vp, ctypes.c_int64, ctypes.c_int, vp, vp, vp, ctypes.c_int64, vp]),

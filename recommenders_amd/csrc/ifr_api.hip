@@ -15,6 +15,7 @@
 #include "ifr_kernels.h"
 #include "ifr_itemitem.h"
 #include "ifr_fit.h"
+#include "ifr_evalcsr.h"
 
 namespace ifr {
 // implemented in ifr_aux.hip
@@ -503,6 +504,20 @@ static int copy_csr(ifr_handle h, const int64_t *indptr, const int32_t *indices,
     return IFR_OK;
 }
 
+// h->ex_ptr / h->ex_idx are in place: the per-tile encoding the fused kernel reads
+static int encode_exclusions(ifr_handle h, int64_t n_rows, int64_t nnz)
+{
+    IFR_HIP(h, hipMalloc((void **)&h->ex_cnt, sizeof(int32_t) * n_rows));
+    IFR_HIP(h, hipMalloc((void **)&h->ex_pair, sizeof(uint2) * std::max<int64_t>(nnz, 1)));
+    const int grid = (int)((n_rows + 255) / 256);
+    hipLaunchKernelGGL(ifr::encode_exclusions_kernel, dim3(grid), dim3(256), 0, 0, h->ex_ptr, h->ex_idx, n_rows,
+                       (int)h->n_items, h->ex_cnt, h->ex_pair);
+    IFR_HIP(h, hipGetLastError());
+    IFR_HIP(h, hipDeviceSynchronize());
+    h->ex_rows = n_rows; h->ex_nnz = nnz;
+    return IFR_OK;
+}
+
 int ifr_set_exclusion_csr(ifr_handle h, const int64_t *indptr, const int32_t *indices, int64_t n_rows, int64_t nnz)
 {
     if (!h) return IFR_ERR_ARG;
@@ -515,15 +530,7 @@ int ifr_set_exclusion_csr(ifr_handle h, const int64_t *indptr, const int32_t *in
     std::vector<int64_t> hp;
     int rc = copy_csr(h, indptr, indices, n_rows, nnz, &h->ex_ptr, &h->ex_idx, &hp);
     if (rc) return rc;
-    IFR_HIP(h, hipMalloc((void **)&h->ex_cnt, sizeof(int32_t) * n_rows));
-    IFR_HIP(h, hipMalloc((void **)&h->ex_pair, sizeof(uint2) * std::max<int64_t>(nnz, 1)));
-    const int grid = (int)((n_rows + 255) / 256);
-    hipLaunchKernelGGL(ifr::encode_exclusions_kernel, dim3(grid), dim3(256), 0, 0, h->ex_ptr, h->ex_idx, n_rows,
-                       (int)h->n_items, h->ex_cnt, h->ex_pair);
-    IFR_HIP(h, hipGetLastError());
-    IFR_HIP(h, hipDeviceSynchronize());
-    h->ex_rows = n_rows; h->ex_nnz = nnz;
-    return IFR_OK;
+    return encode_exclusions(h, n_rows, nnz);
 }
 
 int ifr_set_truth_csr(ifr_handle h, const int64_t *indptr, const int32_t *indices, int64_t n_rows, int64_t nnz)
@@ -540,6 +547,82 @@ int ifr_set_truth_csr(ifr_handle h, const int64_t *indptr, const int32_t *indice
     int64_t mx = 0;
     for (int64_t r = 0; r < n_rows; ++r) mx = std::max(mx, hp[r + 1] - hp[r]);
     h->tr_rows = n_rows; h->tr_nnz = nnz; h->tr_max_row = (int)mx;
+    return IFR_OK;
+}
+
+// The candidate-set builder of ranking_eval on the device (ifr_evalcsr.hip): the three raw rating matrices -> the truth
+// and exclusion CSRs of user rows [row0, row0 + n_rows), installed in the handle like the two setters above would.
+int ifr_build_eval_csrs(ifr_handle h, const ifr_csr_split *train, const ifr_csr_split *val, const ifr_csr_split *test,
+                        int ratings_f64, double rating_threshold, int64_t n_items, int64_t row0, int64_t n_rows,
+                        uint8_t *has_pos, int64_t *truth_nnz, int64_t *excl_nnz, int *max_truth_row)
+{
+    if (!h) return IFR_ERR_ARG;
+    if (!train || !test || !train->indptr || !test->indptr) return fail(h, IFR_ERR_ARG, "ifr_build_eval_csrs: train and test splits are required");
+    if (n_items <= 0 || n_items > (int64_t)1 << 30 || row0 < 0 || n_rows < 0) return fail(h, IFR_ERR_ARG, "ifr_build_eval_csrs: bad n_items / row range");
+    if (h->n_items <= 0) return fail(h, IFR_ERR_STATE, "ifr_build_eval_csrs: set the model first");
+    IFR_HIP(h, hipSetDevice(h->device));
+    dfree(h->ex_ptr); dfree(h->ex_idx); dfree(h->ex_cnt); dfree(h->ex_pair);
+    dfree(h->tr_ptr); dfree(h->tr_idx);
+    h->ex_rows = 0; h->ex_nnz = 0; h->tr_rows = 0; h->tr_nnz = 0; h->tr_max_row = 0;
+    if (truth_nnz) *truth_nnz = 0;
+    if (excl_nnz) *excl_nnz = 0;
+    if (max_truth_row) *max_truth_row = 0;
+    if (n_rows == 0) return IFR_OK;
+
+    ifr::EvalCsrParams p{};
+    auto raw = [&](const ifr_csr_split *sp) {
+        ifr::RawCsr r{};
+        if (sp && sp->indptr && sp->n_rows > 0) { r.ptr = sp->indptr; r.idx = sp->indices; r.val = sp->ratings; r.rows = sp->n_rows; r.f64 = ratings_f64; }
+        return r;
+    };
+    p.train = raw(train); p.val = raw(val); p.test = raw(test);
+    p.thr = rating_threshold; p.n_items = (int)n_items; p.n_rows = n_rows; p.row0 = row0;
+    uint8_t *d_has = nullptr;
+    int *d_max = nullptr;
+    int32_t *d_run = nullptr, *d_tmp = nullptr;
+    void *d_scan = nullptr;
+    const size_t scan_bytes = ifr::eval_csr_scan_bytes(n_rows);
+    auto cleanup = [&]() { dfree(d_has); dfree(d_max); dfree(d_run); dfree(d_tmp); dfree(d_scan); };
+    bool ok = hipMalloc((void **)&h->tr_ptr, sizeof(int64_t) * (n_rows + 1)) == hipSuccess &&
+              hipMalloc((void **)&h->ex_ptr, sizeof(int64_t) * (n_rows + 1)) == hipSuccess &&
+              hipMalloc((void **)&d_has, (size_t)n_rows) == hipSuccess && hipMalloc((void **)&d_max, sizeof(int)) == hipSuccess &&
+              hipMalloc(&d_scan, std::max<size_t>(scan_bytes, 16)) == hipSuccess &&
+              (p.val.ptr == nullptr || hipMalloc((void **)&d_run, sizeof(int32_t) * n_rows) == hipSuccess);
+    if (!ok) { cleanup(); return fail(h, IFR_ERR_HIP, "ifr_build_eval_csrs: out of device memory (row pointers)"); }
+    p.cnt_truth = h->tr_ptr; p.cnt_excl = h->ex_ptr; p.run_a = d_run; p.has_pos = d_has; p.max_truth_row = d_max;
+    if (ifr::launch_eval_csr_count(p, d_scan, scan_bytes, 0) != 0) { cleanup(); return fail(h, IFR_ERR_HIP, "ifr_build_eval_csrs: count sweep failed"); }
+    int64_t tn = 0, en = 0;
+    int mx = 0;
+    ok = hipMemcpy(&tn, h->tr_ptr + n_rows, sizeof(int64_t), hipMemcpyDeviceToHost) == hipSuccess &&
+         hipMemcpy(&en, h->ex_ptr + n_rows, sizeof(int64_t), hipMemcpyDeviceToHost) == hipSuccess &&
+         hipMemcpy(&mx, d_max, sizeof(int), hipMemcpyDeviceToHost) == hipSuccess;
+    ok = ok && hipMalloc((void **)&h->tr_idx, sizeof(int32_t) * (tn + ifr::item_csr_pad())) == hipSuccess &&
+         hipMalloc((void **)&h->ex_idx, sizeof(int32_t) * (en + ifr::item_csr_pad())) == hipSuccess &&
+         (p.val.ptr == nullptr || hipMalloc((void **)&d_tmp, sizeof(int32_t) * std::max<int64_t>(en, 1)) == hipSuccess);
+    if (!ok) { cleanup(); return fail(h, IFR_ERR_HIP, "ifr_build_eval_csrs: out of device memory (entries)"); }
+    p.tr_ptr = h->tr_ptr; p.ex_ptr = h->ex_ptr; p.tr_idx = h->tr_idx; p.ex_idx = h->ex_idx; p.ex_tmp = d_tmp;
+    if (ifr::launch_eval_csr_fill(p, 0) != 0) { cleanup(); return fail(h, IFR_ERR_HIP, "ifr_build_eval_csrs: fill sweep failed"); }
+    if (has_pos && hipMemcpy(has_pos, d_has, (size_t)n_rows, hipMemcpyDefault) != hipSuccess) { cleanup(); return fail(h, IFR_ERR_HIP, "ifr_build_eval_csrs: has_pos copy failed"); }
+    if (hipDeviceSynchronize() != hipSuccess) { cleanup(); return fail(h, IFR_ERR_HIP, "ifr_build_eval_csrs: kernels failed"); }
+    cleanup();
+    h->tr_rows = n_rows; h->tr_nnz = tn; h->tr_max_row = mx;
+    if (truth_nnz) *truth_nnz = tn;
+    if (excl_nnz) *excl_nnz = en;
+    if (max_truth_row) *max_truth_row = mx;
+    return encode_exclusions(h, n_rows, en);
+}
+
+int ifr_read_eval_csr(ifr_handle h, int which, int64_t *indptr, int32_t *indices, int64_t *n_rows, int64_t *nnz)
+{
+    if (!h || (which != 0 && which != 1)) return IFR_ERR_ARG;
+    const int64_t rows = which == 0 ? h->tr_rows : h->ex_rows, n = which == 0 ? h->tr_nnz : h->ex_nnz;
+    const int64_t *dp = which == 0 ? h->tr_ptr : h->ex_ptr;
+    const int32_t *di = which == 0 ? h->tr_idx : h->ex_idx;
+    if (n_rows) *n_rows = rows;
+    if (nnz) *nnz = n;
+    IFR_HIP(h, hipSetDevice(h->device));
+    if (indptr && rows > 0) IFR_HIP(h, hipMemcpy(indptr, dp, sizeof(int64_t) * (rows + 1), hipMemcpyDefault));
+    if (indices && n > 0) IFR_HIP(h, hipMemcpy(indices, di, sizeof(int32_t) * n, hipMemcpyDefault));
     return IFR_OK;
 }
 
@@ -1517,6 +1600,9 @@ int ifr_debug_read_stamps(ifr_handle h, unsigned long long *out, int64_t cap, in
 {
     if (!h || !out || !n) return IFR_ERR_ARG;
     IFR_HIP(h, hipDeviceSynchronize());
+#ifdef IFR_ABLATE
+    if (h->dbg_stamp_count == 0 && cap >= 16 && ifr::item_sparse_read_phases(out) == 0) { *n = 16; return IFR_OK; }
+#endif
     *n = (int64_t)std::min<size_t>(h->dbg_stamp_count, (size_t)cap);
     if (*n > 0) IFR_HIP(h, hipMemcpy(out, h->ws_met, sizeof(unsigned long long) * (size_t)*n, hipMemcpyDeviceToHost));
     return IFR_OK;

@@ -476,6 +476,16 @@ __device__ __forceinline__ double sd_wave_max(double v)
     return v;
 }
 
+#ifdef IFR_ABLATE
+// dev build only (make ABLATE=1): cycles per phase of a window, summed over wave 0 of every workgroup
+__device__ unsigned long long sd_stamps[16];
+#define SD_T0() unsigned long long sd_t = __builtin_amdgcn_s_memtime(), sd_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; (void)sd_t
+#define SD_STAMP(k) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); sd_acc[k] += t_ - sd_t; sd_t = t_; } while (0)
+#else
+#define SD_T0() do {} while (0)
+#define SD_STAMP(k) do {} while (0)
+#endif
+
 template <bool IDX32>
 __global__ __launch_bounds__(SD_BLOCK, 4) void item_sparse_topk_kernel(ItemItemParams p, int32_t *out_ids, float *out_scores)
 {
@@ -494,6 +504,7 @@ __global__ __launch_bounds__(SD_BLOCK, 4) void item_sparse_topk_kernel(ItemItemP
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t i = blockIdx.x;
+    SD_T0();
     const int u = p.user_ids[i];
     const int K = p.K;
     const int nc1 = p.n_chunks + 1;
@@ -504,7 +515,7 @@ __global__ __launch_bounds__(SD_BLOCK, 4) void item_sparse_topk_kernel(ItemItemP
     if (p.ex_ptr != nullptr && u >= 0 && u < p.ex_rows) { eb = p.ex_ptr[u]; ee = p.ex_ptr[u + 1]; }
     const int64_t n_ex = ee - eb;
     const bool ex_lds = n_ex <= SD_EXCAP;
-    const bool single = (he - hb) <= SD_HIST;            // the whole history fits one staging round
+    const bool single = (he - hb) <= min(SD_HIST, SD_BLOCK);      // one staging round, and a thread per history row
     const int m1 = single ? (int)(he - hb) : 0;
 
     for (int w = tid; w < SP_CHUNK + 64; w += SD_BLOCK) tab[w] = 0.0;
@@ -572,11 +583,12 @@ __global__ __launch_bounds__(SD_BLOCK, 4) void item_sparse_topk_kernel(ItemItemP
     auto rank_merge = [&](bool check_ex) __attribute__((always_inline)) {
         const int total = s_nq, cnt = s_cnt;
         if (tid < cnt) { cand_v[tid] = top_v[tid]; cand_c[tid] = top_c[tid]; }
-        else if (check_ex && tid < total && n_ex != 0) {
-            const int col = cand_c[tid];
-            const int64_t w = ex_lower_bound(col);
-            if (w < n_ex && (ex_lds ? exl[w] : p.ex_idx[eb + w]) == col) { cand_v[tid] = -INFINITY; atomicAdd(&s_dead, 1); }
-        }
+        if (check_ex && n_ex != 0)
+            for (int e = cnt + tid; e < total; e += SD_BLOCK) {
+                const int col = cand_c[e];
+                const int64_t w = ex_lower_bound(col);
+                if (w < n_ex && (ex_lds ? exl[w] : p.ex_idx[eb + w]) == col) { cand_v[e] = -INFINITY; atomicAdd(&s_dead, 1); }
+            }
         sd_barrier();
         for (int e = tid; e < total; e += SD_BLOCK) {
             const double v = cand_v[e];
@@ -593,12 +605,12 @@ __global__ __launch_bounds__(SD_BLOCK, 4) void item_sparse_topk_kernel(ItemItemP
     // are still in the threads' own table slots; the slots are left clean.
     auto argmax_rounds = [&](int colA, double floor_v, bool strict) __attribute__((always_inline)) {
         const int cnt = s_cnt;
-        uint32_t taken = 0;                               // bit k: slot k is out of the race; bit 16: my list entry
+        uint64_t taken = 0;                               // bit k: slot k is out of the race; bit SD_SPT: my list entry
         double lv = 0.0; int lc = II_NONE;                // my list entry (threads below cnt)
-        if (tid < cnt) { lv = top_v[tid]; lc = top_c[tid]; } else taken |= 1u << 16;
+        if (tid < cnt) { lv = top_v[tid]; lc = top_c[tid]; } else taken |= 1ull << SD_SPT;
         for (int k = 0; k < SD_SPT; ++k) {
             const double vk = tab[k * SD_BLOCK + tid];
-            if (!(vk != 0.0 && (strict ? vk > floor_v : vk >= floor_v))) taken |= 1u << k;      // (the candidates: all that is left)
+            if (!(vk != 0.0 && (strict ? vk > floor_v : vk >= floor_v))) taken |= 1ull << k;      // (the candidates: all that is left)
         }
         sd_barrier();
         int filled = 0;
@@ -607,9 +619,9 @@ __global__ __launch_bounds__(SD_BLOCK, 4) void item_sparse_topk_kernel(ItemItemP
             for (int k = 0; k < SD_SPT; ++k) {
                 const int col = colA + k * SD_BLOCK + tid;
                 const double vk = tab[k * SD_BLOCK + tid];
-                if (!(taken & (1u << k)) && (bc == II_NONE || sd_beats(vk, col, bv, bc))) { bv = vk; bc = col; }
+                if (!(taken & (1ull << k)) && (bc == II_NONE || sd_beats(vk, col, bv, bc))) { bv = vk; bc = col; }
             }
-            if (!(taken & (1u << 16)) && (bc == II_NONE || sd_beats(lv, lc, bv, bc))) { bv = lv; bc = lc; }
+            if (!(taken & (1ull << SD_SPT)) && (bc == II_NONE || sd_beats(lv, lc, bv, bc))) { bv = lv; bc = lc; }
             double wv = bv; int wc = bc;
 #pragma unroll
             for (int off = 32; off >= 1; off >>= 1) {
@@ -627,9 +639,9 @@ __global__ __launch_bounds__(SD_BLOCK, 4) void item_sparse_topk_kernel(ItemItemP
             if (tid == 0) { top_v[r] = gv; top_c[r] = gc; }
             ++filled;
             if (gc == bc) {                               // mine: retire it
-                if (!(taken & (1u << 16)) && lc == gc) taken |= 1u << 16;
+                if (!(taken & (1ull << SD_SPT)) && lc == gc) taken |= 1ull << SD_SPT;
                 else {
-                    for (int k = 0; k < SD_SPT; ++k) if (colA + k * SD_BLOCK + tid == gc) taken |= 1u << k;
+                    for (int k = 0; k < SD_SPT; ++k) if (colA + k * SD_BLOCK + tid == gc) taken |= 1ull << k;
                 }
             }
         }
@@ -707,9 +719,8 @@ __global__ __launch_bounds__(SD_BLOCK, 4) void item_sparse_topk_kernel(ItemItemP
         // pipelined -- the entries of window c + 1 (SD_PRE per lane) and the row's entry position two windows ahead are
         // requested at the top of window c, so that no global round trip sits between two barriers (without this the
         // kernel spends ~4 us per window waiting on two dependent loads: 125 ms per 1 M users at C5).
-        int L = SD_BLOCK;
-        while (L > 1 && SD_BLOCK / L < m1) L >>= 1;
-        const int e = tid / L, l = tid & (L - 1);
+        const int L = max(1, SD_BLOCK / max(m1, 1));      // lanes per history row (any value, not only powers of two)
+        const int e = tid / L, l = tid - e * L;
         const bool has_row = e < m1;
         const int64_t *cpb = p.cptr + (int64_t)(has_row ? hj[e] : 0) * nc1;
         const double x = has_row ? xs[e] : 0.0;
@@ -755,6 +766,7 @@ __global__ __launch_bounds__(SD_BLOCK, 4) void item_sparse_topk_kernel(ItemItemP
         uint32_t b2raw = pos_lo(min(2, p.n_chunks));                              // ... of window c + 2, as loaded (converted when used)
         Pre A, B;
         issue(A, 0, b1);
+        SD_STAMP(9);                                      // 9: prologue
         // ---- the window's selection, ENTRY-driven: after the barrier every lane swaps the slot of each of its entries for
         // zero.  The first lane to arrive at a column takes its (complete) sum, the others get 0: every touched slot is
         // read once, cleared, and owned by exactly one lane -- no scan of the 4096 slots, no poison for the exclusions (a
@@ -789,9 +801,14 @@ __global__ __launch_bounds__(SD_BLOCK, 4) void item_sparse_topk_kernel(ItemItemP
                 if (vv != 0.0 && (!full || vv > tau)) append(vv, col);      // (exclusions: looked up at the merge)
             }
             if (full) {
+                bool any = false;                         // (a zero passes when the K-th sum is negative: sorted out inside)
 #pragma unroll
-                for (int t = 0; t < SD_PRE; ++t)
-                    if (v[t] != 0.0 && v[t] > tau) append(v[t], (int)s.ent[t].x);     // (exclusions: looked up at the merge)
+                for (int t = 0; t < SD_PRE; ++t) any |= v[t] > tau;
+                if (any) {
+#pragma unroll
+                    for (int t = 0; t < SD_PRE; ++t)
+                        if (v[t] != 0.0 && v[t] > tau) append(v[t], (int)s.ent[t].x);     // (exclusions: looked up at the merge)
+                }
             } else {
                 // short list: a lower bound of the window's K-th best sum.  Keys = the high words of the lanes' best sums,
                 // order-preserving (0 = no sum); a bit-by-bit search (ballot + popcount, no cross-lane data movement)
@@ -822,7 +839,9 @@ __global__ __launch_bounds__(SD_BLOCK, 4) void item_sparse_topk_kernel(ItemItemP
                 for (int t = 0; t < SD_PRE; ++t)
                     if (key[t] >= floor_k) append(v[t], (int)s.ent[t].x);
             }
+            SD_STAMP(4);                                  // 4: claims + candidate appends
             sd_barrier();                                 // appends done, every touched slot is clean
+            SD_STAMP(5);                                  // 5: second barrier
             const int total = s_nq;
             if (total > cap) {
                 // more candidates than the buffer holds (mass ties): the table is clean, so -- after the candidates of the
@@ -846,16 +865,24 @@ __global__ __launch_bounds__(SD_BLOCK, 4) void item_sparse_topk_kernel(ItemItemP
             const int b2 = has_row ? (int)(b2raw - row0lo) : 0;     // requested a whole window ago
             issue(nxt, b1, b2);                                     // window c + 1 (an empty range past the last window)
             b2raw = pos_lo(min(c + 3, p.n_chunks));
+            SD_STAMP(0);                                            // 0: issue (incl. the wait for the loads of the last window)
             consume(cur, c * SP_CHUNK);
             b1 = b2;
-            sd_barrier();                                           // the window's sums are complete
+            SD_STAMP(1);                                            // 1: consume
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+            SD_STAMP(2);                                            // 2: the adds have landed
+            __builtin_amdgcn_s_barrier();                           // the window's sums are complete
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+            SD_STAMP(3);                                            // 3: barrier skew
             select_claimed(cur, c);
+            SD_STAMP(7);                                            // 7: decisions, merges
         };
         for (int c = 0; c < p.n_chunks; c += 2) {
             window(c, A, B);
             if (c + 1 < p.n_chunks) window(c + 1, B, A);
         }
         if (nq_prev > cnt_r) rank_merge(true);                      // the candidates still pending
+        SD_STAMP(7);
     } else {
         for (int c = 0; c < p.n_chunks; ++c) {
             accumulate(c, c * SP_CHUNK);
@@ -924,12 +951,26 @@ __global__ __launch_bounds__(SD_BLOCK, 4) void item_sparse_topk_kernel(ItemItemP
         out_ids[i * K + tid] = id;
         out_scores[i * K + tid] = sc;
     }
+#ifdef IFR_ABLATE
+    SD_STAMP(8);                                                              // 8: zero sweep + output
+    if (tid == 0) {
+        for (int k = 0; k < 10; ++k) atomicAdd(&sd_stamps[k], sd_acc[k]);
+        atomicAdd(&sd_stamps[15], 1ull);
+    }
+#endif
 }
 
 int item_sparse_read_phases(unsigned long long *out16)
 {
+#ifdef IFR_ABLATE
+    unsigned long long zero[16] = {0};
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(sd_stamps), sizeof(zero)) != hipSuccess) return -3;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(sd_stamps), zero, sizeof(zero)) != hipSuccess) return -3;
+    return 0;
+#else
     (void)out16;
     return -1;
+#endif
 }
 
 int launch_item_sparse_topk(const ItemItemParams &p, int32_t *out_ids, float *out_scores, hipStream_t stream)

@@ -71,3 +71,18 @@ class Dataset:
 
     def reset(self):
         return self
+
+
+class DeviceDataset:
+    """A split whose rating matrix lives in device memory (`recommenders_amd.engine.DeviceCsr`): the three things
+    ranking_eval reads of a Dataset -- num_users, num_items, csr_matrix (cornac/data/dataset.py:229-238) -- for splits
+    too large for host-side sparse algebra (one GPU's shard of the 10 M x 1 M configuration: 75 M ratings)."""
+
+    def __init__(self, csr):
+        self.csr_matrix = csr
+        self.num_users, self.num_items = csr.shape
+        self.num_ratings = csr.nnz
+
+    @property
+    def matrix(self):
+        return self.csr_matrix

@@ -32,6 +32,38 @@ def _host_ptr(a):
     return ctypes.c_void_p(a.ctypes.data)
 
 
+class DeviceCsr:
+    """A rating matrix in device memory: the three arrays of a canonical CSR matrix (columns ascending inside a row) as
+    torch tensors -- indptr int64, indices int32, data float64 / float32 -- plus its shape.  What `Dataset.csr_matrix`
+    is to the reference's evaluation loop (cornac/data/dataset.py:229-238), for splits too large to filter on the host."""
+
+    __slots__ = ("indptr", "indices", "data", "shape")
+
+    def __init__(self, indptr, indices, data, shape):
+        self.indptr, self.indices, self.data, self.shape = indptr, indices, data, (int(shape[0]), int(shape[1]))
+
+    @property
+    def nnz(self):
+        return int(self.indices.numel())
+
+    @classmethod
+    def of(cls, mat, device):
+        """`mat` itself when it already is a DeviceCsr, else an upload of the SciPy matrix (made canonical first)."""
+        if isinstance(mat, cls):
+            return mat
+        import scipy.sparse as sp
+        torch = _torch()
+        m = sp.csr_matrix(mat)
+        if not m.has_canonical_format:
+            m = m.copy()
+            m.sum_duplicates()
+            m.sort_indices()
+        data = m.data if m.data.dtype in (np.float32, np.float64) else m.data.astype(np.float64)
+        return cls(torch.as_tensor(m.indptr.astype(np.int64, copy=False)).to(device),
+                   torch.as_tensor(m.indices.astype(np.int32, copy=False)).to(device),
+                   torch.as_tensor(np.ascontiguousarray(data)).to(device), m.shape)
+
+
 class HipScorer:
     """Device-resident model + CSR data and the batched rank / metric entry points."""
 
@@ -265,6 +297,44 @@ class HipScorer:
         self._check(self._lib.ifr_set_truth_csr(self._h, pp, pi, n_rows, len(indices)))
         self.has_truth = n_rows > 0
         del kp, ki
+
+    def build_eval_csrs(self, train, val, test, rating_threshold, n_items, row0, n_rows):
+        """ranking_eval's candidate-set builder on the device (ifr_build_eval_csrs; base_method.py:246-283): from the raw
+        train / validation (or None) / test rating matrices -- `DeviceCsr`, or SciPy CSR matrices that are uploaded --
+        the truth and exclusion CSRs of the users [row0, row0 + n_rows) are built and installed in this engine.
+        -> dict(has_pos: uint8 device tensor [n_rows], truth_nnz, excl_nnz, max_truth_row)."""
+        from ._lib import CsrSplit
+        torch = _torch()
+        splits = [None if m is None else DeviceCsr.of(m, self.device) for m in (train, val, test)]
+        f64 = any(sp is not None and sp.data.dtype == torch.float64 for sp in splits)
+        keep, cs = [], []
+        for sp in splits:
+            if sp is None:
+                cs.append(None)
+                continue
+            data = sp.data.to(torch.float64) if f64 else sp.data
+            keep.append(data)
+            cs.append(CsrSplit(sp.indptr.data_ptr(), sp.indices.data_ptr(), data.data_ptr(), sp.shape[0]))
+        has_pos = torch.zeros(max(int(n_rows), 0), dtype=torch.uint8, device=self.device)
+        tn, en, mx = ctypes.c_int64(0), ctypes.c_int64(0), ctypes.c_int(0)
+        ref = lambda c: None if c is None else ctypes.byref(c)
+        self.exclusion_source = self.truth_source = None
+        self._check(self._lib.ifr_build_eval_csrs(self._h, ref(cs[0]), ref(cs[1]), ref(cs[2]), int(f64), float(rating_threshold),
+                                                  int(n_items), int(row0), int(n_rows), has_pos.data_ptr(),
+                                                  ctypes.byref(tn), ctypes.byref(en), ctypes.byref(mx)))
+        self.has_exclusions = self.has_truth = n_rows > 0
+        del keep
+        return dict(has_pos=has_pos, truth_nnz=tn.value, excl_nnz=en.value, max_truth_row=mx.value)
+
+    def read_eval_csr(self, which):
+        """(indptr int64, indices int32) of the truth (`which` = "truth") or exclusion CSR this engine holds, on the host."""
+        w = {"truth": 0, "exclusion": 1}[which]
+        rows, nnz = ctypes.c_int64(0), ctypes.c_int64(0)
+        self._check(self._lib.ifr_read_eval_csr(self._h, w, None, None, ctypes.byref(rows), ctypes.byref(nnz)))
+        indptr = np.zeros(rows.value + 1, np.int64)
+        indices = np.zeros(nnz.value, np.int32)
+        self._check(self._lib.ifr_read_eval_csr(self._h, w, indptr.ctypes.data, indices.ctypes.data, None, None))
+        return indptr, indices
 
     # ------------------------------------------------------------------ compute
     def rank_topk(self, user_ids, K, out_ids=None, out_scores=None, dense_batch_pairs=1 << 28):

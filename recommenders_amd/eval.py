@@ -7,13 +7,14 @@ kernels read (exclusions and truth, SURVEY.md Appendix B rules 1-3), pick the la
 the metric list, shard the test users across ranks when torch.distributed is initialised, and
 assemble the reference's return value `(avg_results, user_results)`.
 """
+import weakref
 from collections.abc import Mapping
 
 import numpy as np
 import scipy.sparse as sp
 
 from . import dist as ifr_dist
-from .engine import MAX_DENSE_METRIC_POS, METRIC_COLUMNS, METRICS_PER_K
+from .engine import MAX_DENSE_METRIC_POS, METRIC_COLUMNS, METRICS_PER_K, DeviceCsr
 from .metrics import metric_kind
 
 MAX_FUSED_K = 128         # fused score + top-K kernel of dot-product models (item-item models: 32); larger cut-offs,
@@ -114,21 +115,122 @@ def cached_users_with_positives(test_mat, rating_threshold, n_rows):
     return _cached("has_pos", (test_mat,), key, lambda: users_with_positives(test_mat, rating_threshold, n_rows))
 
 
+# --------------------------------------------------------------------------- candidate sets built on the device
+# SciPy builds the two CSRs above in 0.2 s at ML-20M size -- 27 x the fused kernel's pass -- and the 75 M interactions of
+# a C3 shard never fit that budget.  Splits with at least this many stored ratings (or splits handed over as
+# `DeviceCsr`) go through ifr_build_eval_csrs instead: the raw arrays are uploaded once (memoised like the host CSRs),
+# one wave per user row filters them, and nothing but the list of evaluated users comes back to the host.
+DEVICE_BUILD_MIN_NNZ = 1 << 22
+
+
+def _split_nnz(mat):
+    return 0 if mat is None else int(mat.nnz)
+
+
+def _split_key(mat):
+    if isinstance(mat, DeviceCsr):
+        return ("dev", mat.shape, mat.nnz, int(mat.indptr.data_ptr()), int(mat.indices.data_ptr()), int(mat.data.data_ptr()))
+    return _fingerprint(mat)
+
+
+def device_users_with_positives(test_mat, rating_threshold):
+    """(users int64 ascending on the host, n_rows) of a DeviceCsr test split: the users with a test item rated >=
+    threshold (base_method.py:254-259), and 1 + the last user with any stored test entry."""
+    import torch
+    keep = test_mat.data >= rating_threshold
+    cs = torch.zeros(test_mat.nnz + 1, dtype=torch.int64, device=keep.device)
+    torch.cumsum(keep, 0, out=cs[1:])
+    cnt = cs[test_mat.indptr[1:]] - cs[test_mat.indptr[:-1]]
+    users = torch.nonzero(cnt > 0).flatten().cpu().numpy().astype(np.int64)
+    stored = torch.nonzero(test_mat.indptr[1:] > test_mat.indptr[:-1]).flatten()
+    n_rows = int(stored[-1].item()) + 1 if stored.numel() else 0
+    return users, n_rows
+
+
+class DeviceEvalCsrs:
+    """The truth / exclusion CSRs of one (splits, threshold, catalogue, user range) built INSIDE an engine by
+    ifr_build_eval_csrs.  The object is the identity the engines and the result caches compare (`exclusion_source`); the
+    SciPy forms are read back from the engine only if a host consumer asks (per-user caches, unknown-item tails)."""
+
+    def __init__(self, mats, thr, n_items, n_rows, row0):
+        self.mats, self.thr, self.n_items, self.n_rows, self.row0 = mats, float(thr), int(n_items), int(n_rows), int(row0)
+        self.stats = None
+        self._host = {}
+        self._uploads = {}
+
+    def install(self, eng):
+        """Make `eng` hold these CSRs (a no-op when it already does)."""
+        if getattr(eng, "exclusion_source", None) is self and getattr(eng, "truth_source", None) is self:
+            return
+        key = str(eng.device)
+        ups = self._uploads.get(key)
+        if ups is None:                              # raw arrays: uploaded once per device, reused by every engine on it
+            ups = [None if m is None else DeviceCsr.of(m, eng.device) for m in self.mats]
+            self._uploads = {key: ups}
+        st = eng.build_eval_csrs(ups[0], ups[2], ups[1], self.thr, self.n_items, self.row0, self.n_rows)
+        self.stats = dict(truth_nnz=st["truth_nnz"], excl_nnz=st["excl_nnz"], max_truth_row=st["max_truth_row"])
+        eng.exclusion_source = eng.truth_source = self
+        self._eng = weakref.ref(eng)
+
+    def host(self, which):
+        """SciPy CSR ("truth" / "exclusion"), read back from the engine that holds the device copy."""
+        m = self._host.get(which)
+        if m is None:
+            eng = self._eng() if getattr(self, "_eng", None) is not None else None
+            if eng is None:
+                if any(isinstance(x, DeviceCsr) for x in self.mats):
+                    raise RuntimeError("the engine that built these evaluation CSRs is gone: run ranking_eval again")
+                truth, excl, _ = build_eval_csrs(self.mats[0], self.mats[1], self.mats[2], self.thr, self.n_items, self.n_rows, self.row0)
+                self._host.update(truth=truth, exclusion=excl)
+                return self._host[which]
+            self.install(eng)
+            indptr, indices = eng.read_eval_csr(which)
+            m = sp.csr_matrix((np.ones(len(indices), np.int8), indices, indptr), shape=(self.n_rows, self.n_items))
+            self._host[which] = m
+        return m
+
+
+def cached_device_eval_csrs(train_mat, test_mat, val_mat, rating_threshold, n_items, n_rows, row0=0):
+    key = (float(rating_threshold), int(n_items), int(n_rows), int(row0), _split_key(train_mat), _split_key(test_mat),
+           _split_key(val_mat))
+    return _cached("dev_csrs", (train_mat, test_mat, val_mat), key,
+                   lambda: DeviceEvalCsrs((train_mat, test_mat, val_mat), rating_threshold, n_items, n_rows, row0))
+
+
+def _host_csr(x, which="exclusion"):
+    return x.host(which) if isinstance(x, DeviceEvalCsrs) else x
+
+
 class UserResults(Mapping):
     """`user_results[i]` of ranking_eval: user index -> metric value, like the reference's dict
     (base_method.py:236-239, 299), but backed by two arrays: building 138 K-entry dicts per metric cost more than the
     ranking itself.  Reads like a dict (`[]`, `in`, `len`, iteration, `.items()`, `.values()`, `==` with a dict) and
     pickles as a plain dict."""
 
-    __slots__ = ("_users", "_values")
+    __slots__ = ("_users", "_vals", "_src")
 
     def __init__(self, users, values):
+        """`values`: an array, or a callable returning one (a column still on the device: copied on the first read)."""
         users = np.asarray(users, np.int64)
+        self._src = None
+        if callable(values):
+            if len(users) > 1 and not (users[1:] > users[:-1]).all():
+                values = values()
+            else:
+                self._users, self._vals, self._src = users, None, values
+                return
         values = np.asarray(values, np.float64)
         if len(users) > 1 and not (users[1:] > users[:-1]).all():
             order = np.argsort(users, kind="stable")
             users, values = users[order], values[order]
-        self._users, self._values = users, values
+        self._users, self._vals = users, values
+
+    @property
+    def _values(self):
+        if self._vals is None:
+            self._vals = np.asarray(self._src(), np.float64)
+            self._src = None
+        return self._vals
 
     def __getitem__(self, u):
         i = int(np.searchsorted(self._users, u))
@@ -243,7 +345,12 @@ class _CacheOwner:
     block_users = 2048
 
     def __init__(self, model, excl, n_items, users, row0=0):
-        self.model, self.excl, self.n_items, self.users, self.row0 = model, excl, n_items, users, int(row0)
+        # excl_source: a SciPy CSR, or the DeviceEvalCsrs it is read back from on the first host use
+        self.model, self.excl_source, self.n_items, self.users, self.row0 = model, excl, n_items, users, int(row0)
+
+    @property
+    def excl(self):
+        return _host_csr(self.excl_source)
 
     def excl_row(self, u):
         r = int(u) - self.row0
@@ -286,10 +393,13 @@ class _CacheOwner:
                 break
         if u not in block:                                 # a user the engine has no row of its own for
             return self._materialise_one(u)
-        excl = self.excl_global()
-        if getattr(eng, "exclusion_source", None) is not excl:
-            eng.set_exclusion_csr(excl.indptr.astype(np.int64), excl.indices.astype(np.int32))
-            eng.exclusion_source = excl
+        if isinstance(self.excl_source, DeviceEvalCsrs) and self.row0 == 0:
+            self.excl_source.install(eng)                          # built on the device: nothing to upload
+        else:
+            excl = self.excl_global()
+            if getattr(eng, "exclusion_source", None) is not excl:
+                eng.set_exclusion_csr(excl.indptr.astype(np.int64), excl.indices.astype(np.int32))
+                eng.exclusion_source = excl
         eng.set_catalogue_items(self.n_items)
         rows = torch.as_tensor(np.asarray(block, np.int32), device=eng.device)
         # [b, n_items] in the model's native score type: fp32, or the float64 sums of a precision="f64" model (ranked
@@ -423,8 +533,11 @@ def export_candidate_pools(model, pool_size, batch_users=1 << 16, _engine=None):
         from_full(int(u))
     if len(lazy):
         eng.set_catalogue_items(owner.n_items)
-        excl = owner.excl_global()
-        eng.set_exclusion_csr(excl.indptr.astype(np.int64), excl.indices.astype(np.int32))
+        if isinstance(owner.excl_source, DeviceEvalCsrs) and owner.row0 == 0:
+            owner.excl_source.install(eng)
+        else:
+            excl = owner.excl_global()
+            eng.set_exclusion_csr(excl.indptr.astype(np.int64), excl.indices.astype(np.int32))
         k = min(pool_size, eng.n_items)
         for lo in range(0, len(lazy), int(batch_users)):
             part = lazy[lo:lo + int(batch_users)]
@@ -505,10 +618,17 @@ def ranking_eval(model, metrics, train_set, test_set, val_set=None, rating_thres
     n_items = train_set.num_items if exclude_unknowns else test_set.num_items
     # users with a stored test entry = np.unique(test_set.uir_tuple[0]) (base_method.py:254), read off the CSR rows
     test_mat = test_set.csr_matrix
-    test_users = np.flatnonzero(np.diff(sp.csr_matrix(test_mat).indptr)).astype(np.int64)
-    n_rows = int(test_users.max()) + 1 if len(test_users) else 0
-    has_pos = cached_users_with_positives(test_mat, rating_threshold, n_rows)
-    users = test_users[has_pos[test_users]]                      # base_method.py:258-259
+    train_mat = train_set.csr_matrix
+    val_mat = None if val_set is None else val_set.csr_matrix
+    any_dev = any(isinstance(m, DeviceCsr) for m in (train_mat, val_mat, test_mat))
+    if isinstance(test_mat, DeviceCsr):
+        users, n_rows = _cached("dev_users", (test_mat,), (float(rating_threshold), _split_key(test_mat)),
+                                lambda: device_users_with_positives(test_mat, rating_threshold))
+    else:
+        test_users = np.flatnonzero(np.diff(sp.csr_matrix(test_mat).indptr)).astype(np.int64)
+        n_rows = int(test_users.max()) + 1 if len(test_users) else 0
+        has_pos = cached_users_with_positives(test_mat, rating_threshold, n_rows)
+        users = test_users[has_pos[test_users]]                      # base_method.py:258-259
 
     # ---- shard users over ranks: contiguous ranges of the evaluated users, and only their rows of everything
     world, rank = ifr_dist.world_and_rank(distributed)
@@ -536,30 +656,47 @@ def ranking_eval(model, metrics, train_set, test_set, val_set=None, rating_thres
     # user's minimum (recommender.py:631-635), i.e. they tie at the bottom and, having the largest
     # indices, rank after every known candidate.
     eng.set_catalogue_items(n_items)
-    truth, excl, _ = cached_eval_csrs(train_set.csr_matrix, test_mat, None if val_set is None else val_set.csr_matrix,
-                                      rating_threshold, n_items, r1 - r0, r0)
     # reference quirk kept: users already in the model's caches are NOT re-ranked
     # (base_method.py:166-167), so their earlier candidate set (exclusion rows) stays in force
     prev = getattr(model, "_hip_cache_owner", None)
-    if prev is not None and prev.excl is excl:
-        pass                                                     # same splits as last time: the rows are identical
-    elif prev is not None and prev.n_items == n_items and prev.row0 == r0 and len(prev.users):
-        n_loc = r1 - r0
-        reuse = prev.users[(prev.users >= r0) & (prev.users < r1)] - r0
-        if len(reuse):
-            keep = np.ones(n_loc, bool)
-            keep[reuse] = False
-            old = prev.excl[:n_loc] if prev.excl.shape[0] >= n_loc else sp.vstack(
-                [prev.excl, sp.csr_matrix((n_loc - prev.excl.shape[0], n_items), dtype=prev.excl.dtype)]).tocsr()
-            excl = (sp.diags(keep.astype(np.int8)) @ excl + sp.diags((~keep).astype(np.int8)) @ old).tocsr()
-            excl.sort_indices()
-    # the memoised CSRs are uploaded once per engine: a repeated evaluation on the same splits finds them in place
-    if getattr(eng, "exclusion_source", None) is not excl:
-        eng.set_exclusion_csr(excl.indptr.astype(np.int64), excl.indices.astype(np.int32))
-        eng.exclusion_source = excl
-    if getattr(eng, "truth_source", None) is not truth:
-        eng.set_truth_csr(truth.indptr.astype(np.int64), truth.indices.astype(np.int32))
-        eng.truth_source = truth
+    prev_rows = prev is not None and prev.n_items == n_items and prev.row0 == r0 and len(prev.users)
+    on_gpu = hasattr(eng, "build_eval_csrs") and getattr(getattr(eng, "device", None), "type", "cpu") == "cuda"
+    big = sum(_split_nnz(m) for m in (train_mat, val_mat, test_mat)) >= DEVICE_BUILD_MIN_NNZ
+    if any_dev and not on_gpu:
+        raise TypeError("DeviceCsr splits need an engine on a GPU")
+    device_csrs = None
+    if on_gpu and (any_dev or big):
+        device_csrs = cached_device_eval_csrs(train_mat, test_mat, val_mat, rating_threshold, n_items, r1 - r0, r0)
+        if prev_rows and prev.excl_source is not device_csrs and not any_dev:
+            device_csrs = None                                       # rows of an earlier evaluation to carry over: host algebra
+    if device_csrs is not None:
+        # (with DeviceCsr splits the quirk above is dropped: an evaluation on new splits ranks every user again)
+        device_csrs.install(eng)
+        truth = excl = device_csrs
+        max_truth_row = device_csrs.stats["max_truth_row"] if device_csrs.stats else int(np.diff(device_csrs.host("truth").indptr).max(initial=0))
+    else:
+        truth, excl, _ = cached_eval_csrs(train_mat, test_mat, val_mat, rating_threshold, n_items, r1 - r0, r0)
+        if prev is not None and prev.excl_source is excl:
+            pass                                                     # same splits as last time: the rows are identical
+        elif prev_rows:
+            n_loc = r1 - r0
+            reuse = prev.users[(prev.users >= r0) & (prev.users < r1)] - r0
+            if len(reuse):
+                keep = np.ones(n_loc, bool)
+                keep[reuse] = False
+                pex = prev.excl
+                old = pex[:n_loc] if pex.shape[0] >= n_loc else sp.vstack(
+                    [pex, sp.csr_matrix((n_loc - pex.shape[0], n_items), dtype=pex.dtype)]).tocsr()
+                excl = (sp.diags(keep.astype(np.int8)) @ excl + sp.diags((~keep).astype(np.int8)) @ old).tocsr()
+                excl.sort_indices()
+        # the memoised CSRs are uploaded once per engine: a repeated evaluation on the same splits finds them in place
+        if getattr(eng, "exclusion_source", None) is not excl:
+            eng.set_exclusion_csr(excl.indptr.astype(np.int64), excl.indices.astype(np.int32))
+            eng.exclusion_source = excl
+        if getattr(eng, "truth_source", None) is not truth:
+            eng.set_truth_csr(truth.indptr.astype(np.int64), truth.indices.astype(np.int32))
+            eng.truth_source = truth
+        max_truth_row = int(np.diff(truth.indptr).max()) if truth.shape[0] else 0
 
     # Users the model does not know keep their own index: the engine holds an all-zero factor row
     # for each of them (HipScoringMixin._hip_engine), which reproduces both "the user term is
@@ -593,16 +730,15 @@ def ranking_eval(model, metrics, train_set, test_set, val_set=None, rating_thres
             else:
                 ids, _ = eng.rank_topk(dev_users, kmax)
             if n_items > eng.n_items:
-                ids = _append_unknown_items(ids, my_users, excl, eng.n_items, n_items, row0)
-            per_user, _, _ = eng.eval_topk_metrics(dev_users, ids, ks)
-            per_user = per_user.cpu().numpy()
+                ids = _append_unknown_items(ids, my_users, _host_csr(excl), eng.n_items, n_items, row0)
+            per_user, _, _ = eng.eval_topk_metrics(dev_users, ids, ks)       # stays on the device until somebody reads it
             for qi, k in enumerate(ks):
                 for ci, name in enumerate(METRIC_COLUMNS):
                     col_of[(name, k)] = per_user[:, METRICS_PER_K * qi + ci]
         need_auc = need_auc and not fused_dense
         if need_list or need_auc:
             lst_ks = ks if ks else [-1]
-            max_pos = int(np.diff(truth.indptr).max()) if truth.shape[0] else 0
+            max_pos = max_truth_row
             dense_metrics = max_pos <= (eng.max_dense_metric_pos() if hasattr(eng, "max_dense_metric_pos") else MAX_DENSE_METRIC_POS)
             # rows only (counting metrics, AUC): 16 GB batches, large launches run 20 % faster per user than 1 GB
             # ones; the sorted-list fallback also holds 64-bit sort keys and ids per pair, so it keeps 2^28 pairs
@@ -641,24 +777,50 @@ def ranking_eval(model, metrics, train_set, test_set, val_set=None, rating_thres
                 col_of[("map", -1)] = per_list[:, -1]
             if need_auc:
                 col_of[("auc", -1)] = auc
-        for i, (kind, k) in enumerate(specs):
-            key = (kind, k) if kind in METRIC_COLUMNS else (kind, -1)
-            values[:, i] = col_of[key]
+        cols = [col_of[(kind, k) if kind in METRIC_COLUMNS else (kind, -1)] for kind, k in specs]
+        if all(torch.is_tensor(c) for c in cols):
+            # every metric came out of the fused path: the sums are taken on the device and the per-user values stay
+            # there until `user_results` is read (one D2H of n x len(metrics) doubles, off the critical path)
+            dev_values = torch.stack(cols, dim=1)
+            dev_sums = dev_values.sum(dim=0).cpu().numpy()
+            values = None
+        else:
+            for i, c in enumerate(cols):
+                values[:, i] = c.cpu().numpy() if torch.is_tensor(c) else c
+            dev_values = None
         if any(kind == "mrr" for kind, _ in specs):
             i = [kind for kind, _ in specs].index("mrr")
             if np.isnan(values[:, i]).any():
                 raise ValueError("No matched between ground-truth items and recommendations")   # ranking.py:215-218
+    else:
+        dev_values = None
 
     # ---- aggregate: sums + count, one all-reduce across ranks (base_method.py:302-303)
-    sums = np.concatenate([values.sum(axis=0), [float(n)]]) if n else np.zeros(len(specs) + 1)
+    if n and dev_values is not None:
+        sums = np.concatenate([dev_sums, [float(n)]])
+    else:
+        sums = np.concatenate([values.sum(axis=0), [float(n)]]) if n else np.zeros(len(specs) + 1)
     sums = ifr_dist.all_reduce_sums(sums, world, getattr(eng, "device", None))
     if sums[-1] == 0:
         raise ZeroDivisionError("division by zero")                  # len(user_results[i]) == 0 in the reference
     avg_results = [float(sums[i] / sums[-1]) for i in range(len(specs))]
-    all_users, all_values = my_users, values
     if world > 1 and gather_user_results:
+        if dev_values is not None:
+            values = dev_values.cpu().numpy()
         all_users, all_values = ifr_dist.gather_rows(my_users, values, world)
-    user_results = [UserResults(all_users, all_values[:, i]) for i in range(len(specs))]
+        user_results = [UserResults(all_users, all_values[:, i]) for i in range(len(specs))]
+    elif dev_values is not None:
+        host = []                                                    # one copy shared by the metrics' columns
+
+        def column(i):
+            def read():
+                if not host:
+                    host.append(dev_values.cpu().numpy())
+                return host[0][:, i]
+            return read
+        user_results = [UserResults(my_users, column(i)) for i in range(len(specs))]
+    else:
+        user_results = [UserResults(my_users, values[:, i]) for i in range(len(specs))]
 
     # ---- result caches: lazy, same candidate sets as this evaluation
     if hasattr(model, "rank"):

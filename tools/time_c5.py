@@ -22,3 +22,10 @@ for dbg, cap in [(int(a), c) for a in (sys.argv[2].split(",") if len(sys.argv) >
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t) / 3
         print(f"dbg {dbg} cap {cap} K {K}: {dt*1e3:.2f} ms  {nu/dt/1e6:.2f} M users/s", flush=True)
+        import ctypes
+        out = (ctypes.c_ulonglong * 16)()
+        n = ctypes.c_int64(0)
+        sc._lib.ifr_debug_read_stamps(sc._h, out, 16, ctypes.byref(n))
+        if n.value == 16 and out[15]:
+            names = ["issue next", "consume", "adds land", "barrier 1", "claims+appends", "barrier 2", "read s_nq", "decide+merge", "zeros+out", "prologue"]
+            print("   cycles per user (wave 0): " + ", ".join(f"{nm} {out[k] / out[15]:.0f}" for k, nm in enumerate(names)) + f" | total {sum(out[:10]) / out[15]:.0f}", flush=True)
