@@ -395,8 +395,8 @@ def c_score_item_dense(M, h_idx, h_val, col_scale=None):
     """orc_score_item_dense: fp32 fma chain over the history in order, then * col_scale."""
     M = np.ascontiguousarray(M, np.float32)
     h_idx, h_val, cs = _i32(h_idx), _f32(h_val), _f32(col_scale)
-    out = np.empty(M.shape[0], np.float32)
-    c_lib().orc_score_item_dense(_p(M, ctypes.c_float), ctypes.c_int64(M.shape[1]), M.shape[0],
+    out = np.empty(M.shape[1], np.float32)          # (M may hold only the rows the history indexes: [R, n_items])
+    c_lib().orc_score_item_dense(_p(M, ctypes.c_float), ctypes.c_int64(M.shape[1]), M.shape[1],
                                  _p(h_idx, ctypes.c_int32), _p(h_val, ctypes.c_float), len(h_idx),
                                  _p(cs, ctypes.c_float), _p(out, ctypes.c_float))
     return out
