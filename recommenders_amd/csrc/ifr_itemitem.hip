@@ -450,7 +450,7 @@ constexpr int SD_EXCAP = 256;                           // exclusion row entries
 constexpr int SD_CAND = 256;                            // candidate buffer: the list + new candidates of a window
 constexpr int SD_MAXK = 32;
 constexpr int SD_FLOOR_BITS = 18;                       // bits of the short-list bound (sign + exponent + 6 of the mantissa)
-constexpr int SD_LAZY = 24;                             // pending candidates that trigger a merge
+constexpr int SD_LAZY = 16;                             // (+ K) pending candidates trigger a merge
 constexpr double SD_MAGIC = 6755399441055744.0;         // 1.5 * 2^52: x + MAGIC - MAGIC = x rounded to the nearest-even integer, |x| < 2^51
 constexpr double SD_POISON = -1152921504606846976.0;    // -2^60: an excluded column
 constexpr double SD_LIVE = -288230376151711744.0;       // -2^58: sums above are real (|sum| < 2^52)
@@ -854,9 +854,9 @@ __global__ __launch_bounds__(SD_BLOCK, 4) void item_sparse_topk_kernel(ItemItemP
                 accumulate_rows(m1, c, colA);
                 scan_and_select(colA);
                 cnt_r = s_cnt; tau = top_v[K - 1]; nq_prev = cnt_r;
-            } else if (total > cnt_r && (!full || total - cnt_r >= SD_LAZY || total + SD_LAZY > cap)) {
+            } else if (total > cnt_r && (!full || total - cnt_r >= SD_LAZY + K || total + SD_LAZY + K > cap)) {
                 // LAZY merge: while the list is full, new candidates wait behind it (the stale K-th sum only admits a few
-                // more) until SD_LAZY of them are pending: ~4 merges per user instead of one in every second window
+                // more) until SD_LAZY + K of them are pending: ~4 merges per user instead of one in every second window
                 rank_merge(true);
                 cnt_r = s_cnt; tau = top_v[K - 1]; nq_prev = cnt_r;
             } else nq_prev = total;
