@@ -39,9 +39,10 @@ PEAK_HBM_GBS = 8000.0            # same guide: HBM3E ~8 TB/s
 PROFILED = {"c2_wmf_ml20m": ("r01_c2_pmc.json", 138493, 26744), "c4_ease_mind": ("r01_c4_pmc.json", 262144, 50000),
             "c5_rp3_ebnerd": ("r01_c5_pmc.json", 1048576, 125000), "c3_mf_shard": ("r02_c3_pmc.json", 1250000, 1000000)}
 for _cfg in list(PROFILED):           # a newer round's profile of the same command wins
-    _r2 = PROFILED[_cfg][0].replace("r01_", "r02_")
-    if os.path.exists(os.path.join(ROOT, "profiles", _r2)):
-        PROFILED[_cfg] = (_r2,) + PROFILED[_cfg][1:]
+    _base = PROFILED[_cfg][0].split("_", 1)[1]
+    for _rnd in ("r02", "r03"):
+        if os.path.exists(os.path.join(ROOT, "profiles", f"{_rnd}_{_base}")):
+            PROFILED[_cfg] = (f"{_rnd}_{_base}",) + PROFILED[_cfg][1:]
 
 
 def host_threads():
@@ -354,7 +355,7 @@ def run_config(config, args, steps, warmup, world, rank, dev, D, with_cpu, var):
         if not dense:
             # the HBM roof is the contract's statement for this byte-moving path; what limits the kernel is instruction
             # issue (constants of the committed counter run, like `traffic`)
-            roof["limiter"] = "see profiles/r03_c5_sq_counters.json (round 2's hash-pass kernel: VALU issue, profiles/r02_c5_sq_counters.json)"
+            roof["limiter"] = "no single pipe: a dependent LDS / barrier chain per 4096-column window, see profiles/r03_c5_sq_counters.json"
         cfg = {"workload": workload, "users_per_gpu": n, "items": w["n_items"], "topk": TOPK,
                "parallelism": f"users sharded x{world}, item matrix replicated"}
     else:
