@@ -352,6 +352,10 @@ def run_config(config, args, steps, warmup, world, rank, dev, D, with_cpu, var):
                 "frac": achieved / PEAK_HBM_GBS, "traffic": traffic, "traffic_source": traffic_source,
                 "kernel": "item_item_kernel" if dense else "item_sparse_topk_kernel", "avg_launch_ms": avg_ms, "launches": launches,
                 "bytes_per_launch": bytes_per_launch}
+        if dense:
+            roof["note"] = ("algorithmic rate (4 or 8 bytes per entry of every history row): rows of B that concurrently scored users "
+                            "share are served from L2 / Infinity Cache, so it can exceed what HBM delivers (about 6.3 TB/s measured); "
+                            "`traffic` is the HBM-side byte count of the committed counter pass")
         if not dense:
             # the HBM roof is the contract's statement for this byte-moving path; what limits the kernel is instruction
             # issue (constants of the committed counter run, like `traffic`)

@@ -56,7 +56,9 @@ const char *ifr_last_error(ifr_handle h);
  * ("pair_max": largest K of the pair path, default 100, at most 128);
  * "wide_chunk_cap", "wide_stats": tuning / statistics of that path; "item_f64": see ifr_fit_ease (none of these
  * changes a result);
- * "debug_mode" / "csr_pass_entries": development ablations (results may change; the fused kernel's modes, bits 0-2
+ * "csr_cand_cap": candidate buffer entries of the CSR top-K kernel (64 ... 256, 0 = default 256; tests shrink it to
+ * force the overflow path; no result changes);
+ * "debug_mode": development ablations (results may change; the fused kernel's modes, bits 0-2
  * and 7 of "debug_mode", exist only in a library built with `make ABLATE=1` / `STAMPS=1` and are refused with
  * IFR_ERR_ARG otherwise; bit 6 = one workgroup per CU works everywhere).  Options are per handle and
  * set only through this call: the library reads no environment variable. */
@@ -85,10 +87,13 @@ int ifr_set_user_factors(ifr_handle h, const float *U, int64_t n_users, int k, c
  *   dense:  M [n_items][ld] row-major fp32, ld >= n_items.  Per (user, item) one fp32 fma chain
  *           over the history row in its CSR order, then one fp32 multiply by col_scale.
  *   csr:    rows of M with strictly ascending columns.  Products are exact (fp64), scaled by
- *           2^shift (ifr_item_fixed_point_shift), rounded to nearest even and summed as 64-bit
- *           integers, so the result does not depend on summation order; the sum is rounded once
- *           to fp64 and once to fp32.  col_scale is folded into the stored values when the matrix
- *           is set (M'[j,c] = fl32(M[j,c] * col_scale[c])); a score that is exactly 0 is still
+ *           2^shift (ifr_item_fixed_point_shift: every product and partial sum stays an integer
+ *           below 2^51), rounded to nearest even and summed exactly, so the result does not depend
+ *           on summation order.  RANKING uses those exact sums (sum descending, item ascending):
+ *           ifr_rank_topk rounds only its K winners to fp32, ifr_score_dense_f64 returns the sums
+ *           scaled back (exact in fp64) and the *_f64 row consumers rank them; ifr_score_dense
+ *           rounds each once to fp32.  col_scale is folded into the stored values when the matrix
+ *           is set (M'[j,c] = fl32(M[j,c] * col_scale[c])); a sum that is exactly 0 is still
  *           multiplied by col_scale[c], so that 0 * inf = NaN as in the reference.
  * col_scale: [n_items] or NULL.  "any" pointers. */
 int ifr_set_item_matrix_dense(ifr_handle h, const float *M, int64_t n_items, int64_t ld, const float *col_scale);
