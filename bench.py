@@ -350,7 +350,7 @@ def run_config(config, args, steps, warmup, world, rank, dev, D, with_cpu, var):
                     + f", top-{TOPK} + NDCG@{TOPK}/Recall@{TOPK}/Precision@{TOPK}")
         roof = {"bound": "hbm", "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                 "frac": achieved / PEAK_HBM_GBS, "traffic": traffic, "traffic_source": traffic_source,
-                "kernel": "item_item_kernel" if dense else "item_sparse_topk_kernel", "avg_launch_ms": avg_ms, "launches": launches,
+                "kernel": "item_item_kernel" if dense else "item_sparse_wave_kernel + item_sparse_topk_kernel (the users it hands over)", "avg_launch_ms": avg_ms, "launches": launches,
                 "bytes_per_launch": bytes_per_launch}
         if dense:
             roof["note"] = ("algorithmic rate (4 or 8 bytes per entry of every history row): rows of B that concurrently scored users "

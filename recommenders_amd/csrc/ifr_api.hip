@@ -82,6 +82,9 @@ struct ifr_handle_s {
     int opt_item_f64 = 0;        // ifr_fit_ease installs B in fp64
     int64_t *ii_cptr = nullptr; int32_t *ii_idx = nullptr; float *ii_val = nullptr; int64_t ii_nnz = 0;
     uint2 *ii_pair = nullptr;    // CSR entries as interleaved (column, value) pairs: what the CSR top-K kernel streams
+    uint32_t *ii_cptr_w = nullptr; int ii_n_win = 0;   // entry offsets per 1024-column window (wave-per-user CSR top-K kernel), or null
+    void *ws_long = nullptr; size_t ws_long_bytes = 0;  // users that kernel hands over: [0] = count, then the list
+    int opt_csr_wave = 1;        // 0: CSR top-K by the workgroup-per-user kernel only
     float *ii_pen = nullptr;
     int ii_chunks = 0;
     float ii_maxabs = 0.f;
@@ -297,7 +300,7 @@ int64_t catalogue_items(ifr_handle h) { return h->opt_catalogue > h->n_items ? h
 
 void clear_item_model(ifr_handle h)
 {
-    dfree(h->iiM); dfree(h->iiM64); dfree(h->ii_cptr); dfree(h->ii_idx); dfree(h->ii_val); dfree(h->ii_pen); dfree(h->ii_pair);
+    dfree(h->iiM); dfree(h->iiM64); dfree(h->ii_cptr); dfree(h->ii_idx); dfree(h->ii_val); dfree(h->ii_pen); dfree(h->ii_pair); dfree(h->ii_cptr_w); h->ii_n_win = 0;
     dfree(h->hs_ptr); dfree(h->hs_idx); dfree(h->hs_val);
     h->ii_ld = 0; h->ii_nnz = 0; h->ii_chunks = 0; h->ii_maxabs = 0.f;
     h->hs_rows = 0; h->hs_nnz = 0; h->hs_l1max = 0.f;
@@ -390,9 +393,9 @@ int ifr_destroy(ifr_handle h)
     dfree(h->U); dfree(h->V); dfree(h->ibase); dfree(h->ubase);
     dfree(h->ex_ptr); dfree(h->ex_idx); dfree(h->ex_cnt); dfree(h->ex_pair);
     dfree(h->tr_ptr); dfree(h->tr_idx); dfree(h->discount);
-    dfree(h->iiM); dfree(h->iiM64); dfree(h->ii_cptr); dfree(h->ii_idx); dfree(h->ii_val); dfree(h->ii_pen); dfree(h->ii_pair);
+    dfree(h->iiM); dfree(h->iiM64); dfree(h->ii_cptr); dfree(h->ii_idx); dfree(h->ii_val); dfree(h->ii_pen); dfree(h->ii_pair); dfree(h->ii_cptr_w); h->ii_n_win = 0;
     dfree(h->hs_ptr); dfree(h->hs_idx); dfree(h->hs_val);
-    dfree(h->ws_part); dfree(h->ws_met); dfree(h->ws_sort);
+    dfree(h->ws_part); dfree(h->ws_met); dfree(h->ws_sort); dfree(h->ws_long);
     ifr::ease_release(&h->rocblas);
     ifr::rp3_release(&h->rocsparse);
     for (auto &e : h->ev_used) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
@@ -421,6 +424,7 @@ int ifr_set_option(ifr_handle h, const char *name, int64_t value)
 #endif
         h->opt_debug = (int)value;
     }
+    else if (!strcmp(name, "csr_wave")) h->opt_csr_wave = value != 0;
     else if (!strcmp(name, "csr_cand_cap")) h->opt_csr_pass = value <= 0 ? 0 : (int)std::max<int64_t>(ifr::item_sparse_min_capacity(), std::min<int64_t>(value, ifr::item_sparse_pass_capacity()));
     else if (!strcmp(name, "catalogue_items")) {
         if (value != 0 && (value < h->n_items || value > (int64_t)1 << 30))
@@ -792,6 +796,15 @@ int ifr_set_item_matrix_csr(ifr_handle h, const int64_t *indptr, const int32_t *
                 hipMemset(h->ii_pair, 0, sizeof(uint2) * np) != hipSuccess) lrc = -4;
             else if (nnz > 0) lrc = ifr::launch_interleave_csr(h->ii_idx, h->ii_val, nnz, h->ii_pair, 0);
         }
+        if (!lrc) {                              // entry offsets per 1024-column window, where the table stays modest
+            const int n_win = ifr::item_sparse_wave_windows((int)n_items);
+            const size_t wbytes = sizeof(uint32_t) * (size_t)n_items * (size_t)(n_win + 1);
+            if (wbytes <= ((size_t)1 << 30) && nnz + ifr::item_csr_pad() < ((int64_t)1 << 30) &&
+                hipMalloc((void **)&h->ii_cptr_w, wbytes) == hipSuccess) {
+                h->ii_n_win = n_win;
+                lrc = ifr::launch_build_win_ptr(h->ii_cptr, n_chunks, h->ii_idx, n_items, n_win, h->ii_cptr_w, 0);
+            }
+        }
     }
     if (lrc || hipDeviceSynchronize() != hipSuccess ||
         hipMemcpy(flags, d_flags, sizeof(flags), hipMemcpyDeviceToHost) != hipSuccess) {
@@ -951,6 +964,12 @@ static int rank_topk_item_item(ifr_handle h, const int32_t *user_ids, int64_t n,
     p.K = K; p.KL = KL;
     std::pair<hipEvent_t, hipEvent_t> ev;
     if (h->mode == MODE_ITEM_CSR) {                  // one workgroup per user, final lists written directly
+        if (h->ii_cptr_w != nullptr && h->opt_csr_wave) {
+            rc = grow(h, &h->ws_long, &h->ws_long_bytes, sizeof(int32_t) * ((size_t)n + 1));
+            if (rc) return rc;
+            p.cptr_w = h->ii_cptr_w; p.n_win = h->ii_n_win;
+            p.long_cnt = (int *)h->ws_long; p.long_list = (int32_t *)h->ws_long + 1;
+        }
         rc = prof_begin(h, s, &ev);
         if (rc) return rc;
         if (ifr::launch_item_sparse_topk(p, out_ids, out_scores, s)) return fail(h, IFR_ERR_HIP, "ifr_rank_topk: item-item launch failed");

@@ -16,6 +16,10 @@ struct ItemItemParams {
     int64_t m_nnz;               //         entries in m_idx / m_val
     int fx_shift;                //         fixed-point scale 2^fx_shift
     int dbg;                     // dev-only ablation bits (handle option debug_mode)
+    const uint32_t *cptr_w;      //         [n_items][n_win + 1] entry offsets per 1024-column window (wave-per-user kernel), or null
+    int n_win;
+    int32_t *long_list;          //         users the wave-per-user kernel hands over to the workgroup kernel [n], and their count
+    int *long_cnt;
     int sp_cap;                  //         CSR top-K: candidate buffer entries in use (item_sparse_min_capacity() .. item_sparse_pass_capacity())
     const float *pen;            // [>= n_chunks * chunk] column scale or null (CSR: already folded into m_val,
                                  // kept for the 0 * col_scale = NaN rule of exact zeros)
@@ -44,6 +48,8 @@ int launch_item_item(const ItemItemParams &p, bool sparse, bool topk, hipStream_
 int launch_merge_topk_f64(const double *part_scores, const int32_t *part_ids, int64_t n, int n_lists, int KL, int K, int32_t *out_ids,
                           float *out_scores, hipStream_t stream);
 int launch_item_sparse_topk(const ItemItemParams &p, int32_t *out_ids, float *out_scores, hipStream_t stream);
+int item_sparse_wave_windows(int n_items);
+int launch_build_win_ptr(const int64_t *cptr, int n_chunks, const int32_t *idx, int64_t n_rows, int n_win, uint32_t *cw, hipStream_t s);
 int item_sparse_pass_capacity();
 int item_sparse_min_capacity();
 int item_sparse_read_phases(unsigned long long *out16);   // dev build only (make ABLATE=1), else -1

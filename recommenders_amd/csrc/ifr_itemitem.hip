@@ -486,7 +486,7 @@ __device__ unsigned long long sd_stamps[16];
 #define SD_STAMP(k) do {} while (0)
 #endif
 
-template <bool IDX32>
+template <bool IDX32, bool LIST>
 __global__ __launch_bounds__(SD_BLOCK, 4) void item_sparse_topk_kernel(ItemItemParams p, int32_t *out_ids, float *out_scores)
 {
     __shared__ __attribute__((aligned(16))) double tab[SP_CHUNK + 64];        // + a dummy slot per lane
@@ -503,7 +503,13 @@ __global__ __launch_bounds__(SD_BLOCK, 4) void item_sparse_topk_kernel(ItemItemP
     __shared__ int s_nq, s_cnt, s_dead;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t i = blockIdx.x;
+    // direct mode: workgroup b ranks user b.  LIST mode: the wave-per-user kernel below handed over the
+    // users it does not serve; the workgroups of a fixed-size grid take them in turns.
+    const int64_t limit = LIST ? (int64_t)*p.long_cnt : p.n;
+    int64_t it = blockIdx.x;
+    if (it >= limit) return;
+    do {
+    const int64_t i = LIST ? (int64_t)p.long_list[it] : it;
     SD_T0();
     const int u = p.user_ids[i];
     const int K = p.K;
@@ -958,6 +964,250 @@ __global__ __launch_bounds__(SD_BLOCK, 4) void item_sparse_topk_kernel(ItemItemP
         atomicAdd(&sd_stamps[15], 1ull);
     }
 #endif
+    if (LIST) sd_barrier();                                                   // (the shared state is reused)
+    } while (LIST && (it += gridDim.x) < limit);
+}
+
+// ------------------------------------------------------------------------------------
+// The same sweep with ONE WAVE per user (round 3, last step): the workgroup-per-user kernel above spends its time in a
+// dependent chain per window -- adds, LDS drain, barrier, exchanges, barrier, counter read -- that only the four
+// workgroups a CU holds can overlap, and all four waves of a workgroup execute the same scalar bookkeeping.  A user
+// with at most 64 history rows needs neither: a wave keeps a row per lane, a private table of 1 024 direct-mapped fp64
+// accumulators (8 KB) and its candidate buffer; nothing crosses waves, so there is no s_barrier and no shared counter
+// -- candidate slots come from a ballot prefix -- and a CU holds 16 independent users.  Arithmetic, exchange-claim
+// selection, lazy merges and the exact-domain ranking are those of the kernel above (same results bit for bit).
+// What this kernel does not serve it hands to the workgroup kernel through p.long_list: histories beyond 64 rows,
+// users whose list ends short or with a K-th sum <= 0 (zero-sum columns may rank: the sweep over them lives there),
+// and a candidate buffer that overflows (mass ties).
+// ------------------------------------------------------------------------------------
+constexpr int SW_WIN = 1024;                            // columns per window
+constexpr int SW_PRE = 3;                               // entries per lane prefetched one window ahead
+constexpr int SW_CAND = 96;                             // the list + pending candidates
+constexpr int SW_EXL = 32;                              // exclusion row entries kept in LDS
+constexpr int SW_WAVES = 4;
+
+struct SwLds {
+    double tab[SW_WIN + 64];                            // + a dummy slot per lane
+    double cv[SW_CAND];
+    int cc[SW_CAND];
+    int exl[SW_EXL];
+};
+
+__device__ __forceinline__ void sw_lds_order()
+{
+    // LDS operations of one wave are performed in order, but the compiler must not move them across this point, and the
+    // returning ones must have landed: wait for the wave's outstanding LDS traffic
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+    __builtin_amdgcn_s_waitcnt(0xC07F);                 // lgkmcnt(0)
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+}
+
+__global__ __launch_bounds__(64 * SW_WAVES, 4) void item_sparse_wave_kernel(ItemItemParams p, int32_t *out_ids, float *out_scores)
+{
+    __shared__ __attribute__((aligned(16))) SwLds lds[SW_WAVES];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    SwLds &S = lds[wave];
+    const int64_t i = (int64_t)blockIdx.x * SW_WAVES + wave;
+    if (i >= p.n) return;                                // (the whole wave)
+    const int u = p.user_ids[i];
+    const int K = p.K;
+    const int n_win = p.n_win;
+    const unsigned long long below = (1ull << lane) - 1ull;
+
+    int64_t hb = 0, he = 0, eb = 0, ee = 0;
+    if (u >= 0 && u < p.h_rows) { hb = p.h_ptr[u]; he = p.h_ptr[u + 1]; }
+    if (p.ex_ptr != nullptr && u >= 0 && u < p.ex_rows) { eb = p.ex_ptr[u]; ee = p.ex_ptr[u + 1]; }
+    const int64_t n_ex = ee - eb;
+    const bool ex_lds = n_ex <= SW_EXL;
+    auto hand_over = [&]() __attribute__((always_inline)) {
+        if (lane == 0) p.long_list[atomicAdd(p.long_cnt, 1)] = (int32_t)i;
+    };
+    if (he - hb > 64 || he == hb) { hand_over(); return; }      // (no history: only zero-sum columns to rank)
+    const int m = (int)(he - hb);
+
+    for (int w = lane; w < SW_WIN + 64; w += 64) S.tab[w] = 0.0;
+    if (ex_lds) for (int w = lane; w < (int)n_ex; w += 64) S.exl[w] = p.ex_idx[eb + w];
+    auto excluded = [&](int col) __attribute__((always_inline)) -> bool {
+        int64_t lo = 0, hi = n_ex;
+        if (ex_lds) { while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (S.exl[mid] < col) lo = mid + 1; else hi = mid; } }
+        else { while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (p.ex_idx[eb + mid] < col) lo = mid + 1; else hi = mid; } }
+        return lo < n_ex && (ex_lds ? S.exl[lo] : p.ex_idx[eb + lo]) == col;
+    };
+
+    // a lane keeps ONE history row for the whole sweep: L lanes share a row's segment of a window
+    const int L = max(1, 64 / max(m, 1));
+    const int e = lane / L, l = lane - e * L;
+    const bool has_row = e < m;
+    const int hj = has_row ? p.h_idx[hb + e] : 0;
+    const double x = has_row ? ldexp((double)p.h_val[hb + e], p.fx_shift) : 0.0;
+    const uint32_t *const cw = p.cptr_w + (int64_t)hj * (n_win + 1);          // entry offsets of the row per window
+    const uint32_t base32 = has_row ? (uint32_t)p.cptr[(int64_t)hj * (p.n_chunks + 1)] : 0u;    // the row's first entry (< 2^30 entries in all)
+    const uint2 *const rp = p.m_pair;
+    struct Pre { uint2 ent[SW_PRE]; int first, end; };
+    auto issue = [&](Pre &s, int qa, int qb) __attribute__((always_inline)) {
+        const int last = max(qb - 1, 0);
+#pragma unroll
+        for (int t = 0; t < SW_PRE; ++t) s.ent[t] = rp[base32 + (uint32_t)min(qa + l + t * L, last)];
+        s.first = qa + l;
+        s.end = qb;
+    };
+    auto consume = [&](const Pre &s, int colA) __attribute__((always_inline)) {
+#pragma unroll
+        for (int t = 0; t < SW_PRE; ++t) {
+            const bool ok = s.first + t * L < s.end;
+            const double r = fma(x, (double)__uint_as_float(s.ent[t].y), SD_MAGIC) - SD_MAGIC;
+            atomicAdd(&S.tab[ok ? (int)s.ent[t].x - colA : SW_WIN + lane], ok ? r : 0.0);
+        }
+        for (int q = s.first + SW_PRE * L; q < s.end; q += L) {            // segments longer than the prefetch (rare)
+            const uint2 e2 = rp[base32 + (uint32_t)q];
+            atomicAdd(&S.tab[(int)e2.x - colA], fma(x, (double)__uint_as_float(e2.y), SD_MAGIC) - SD_MAGIC);
+        }
+    };
+    auto claim = [&](int slot) __attribute__((always_inline)) -> double {
+        return __longlong_as_double((long long)atomicExch(reinterpret_cast<unsigned long long *>(&S.tab[slot]), 0ull));
+    };
+
+    // list = cv/cc[0, cnt) (sorted), pending candidates behind it up to nq: wave-uniform registers, no shared counter
+    int cnt = 0, nq = 0;
+    bool over = false;
+    double tau = 0.0;
+    auto append = [&](bool c, double v, int col) __attribute__((always_inline)) {
+        const unsigned long long b = __ballot(c);
+        if (b != 0ull) {
+            const int pos = nq + __popcll(b & below);
+            if (c && pos < SW_CAND) { S.cv[pos] = v; S.cc[pos] = col; }
+            nq += __popcll(b);
+            over |= nq > SW_CAND;
+        }
+    };
+    // the list U the pending candidates -> the new list, by counting (in place: every rank is computed before any write)
+    auto merge = [&]() __attribute__((always_inline)) {
+        sw_lds_order();
+        const int total = nq;
+        const int e0 = lane, e1 = lane + 64;
+        double v0 = -INFINITY, v1 = -INFINITY;
+        int c0 = 0, c1 = 0;
+        if (e0 < total) { v0 = S.cv[e0]; c0 = S.cc[e0]; }
+        if (e1 < total) { v1 = S.cv[e1]; c1 = S.cc[e1]; }
+        // the new candidates are looked up in the user's exclusion row only here
+        if (n_ex != 0) {
+            if (e0 >= cnt && e0 < total && excluded(c0)) { v0 = -INFINITY; S.cv[e0] = -INFINITY; }
+            if (e1 >= cnt && e1 < total && excluded(c1)) { v1 = -INFINITY; S.cv[e1] = -INFINITY; }
+        }
+        const int dead = __popcll(__ballot(e0 >= cnt && e0 < total && v0 == -INFINITY)) + __popcll(__ballot(e1 >= cnt && e1 < total && v1 == -INFINITY));
+        sw_lds_order();
+        int r0 = 0, r1 = 0;
+        for (int q = 0; q < total; ++q) {
+            const double vq = S.cv[q];
+            const int cq = S.cc[q];
+            r0 += sd_beats(vq, cq, v0, c0) ? 1 : 0;
+            r1 += sd_beats(vq, cq, v1, c1) ? 1 : 0;
+        }
+        sw_lds_order();
+        if (e0 < total && r0 < K && v0 != -INFINITY) { S.cv[r0] = v0; S.cc[r0] = c0; }
+        if (e1 < total && r1 < K && v1 != -INFINITY) { S.cv[r1] = v1; S.cc[r1] = c1; }
+        sw_lds_order();
+        cnt = min(K, total - dead);
+        nq = cnt;
+        tau = S.cv[K - 1];                                // (meaningful once cnt == K)
+    };
+
+    Pre A, B;
+    int b1 = has_row ? (int)cw[1] : 0;
+    uint32_t b2raw = cw[min(2, n_win)];
+    issue(A, 0, b1);
+    auto window = [&](int c, const Pre &cur, Pre &nxt) __attribute__((always_inline)) {
+        const int colA = c * SW_WIN;
+        const int b2 = has_row ? (int)b2raw : 0;
+        issue(nxt, b1, b2);                               // window c + 1 (an empty range past the last window)
+        b2raw = cw[min(c + 3, n_win)];
+        consume(cur, colA);
+        b1 = b2;
+        sw_lds_order();                                   // the window's sums are complete (all lanes' adds precede the exchanges)
+        const bool full = cnt == K;
+        double v[SW_PRE];
+#pragma unroll
+        for (int t = 0; t < SW_PRE; ++t) {
+            const bool ok = cur.first + t * L < cur.end;
+            v[t] = claim(ok ? (int)cur.ent[t].x - colA : SW_WIN + lane);
+        }
+        for (int q = cur.first + SW_PRE * L; __any(q < cur.end); q += L) {    // (rare; wave-uniform trip count for the ballots)
+            const bool in = q < cur.end;
+            const int col = in ? (int)rp[base32 + (uint32_t)q].x : 0;
+            const double vv = in ? claim(col - colA) : 0.0;
+            append(in && vv != 0.0 && (!full || vv > tau), vv, col);
+        }
+        if (full) {
+            bool any = false;                             // (a zero passes when the K-th sum is negative: sorted out inside)
+#pragma unroll
+            for (int t = 0; t < SW_PRE; ++t) any |= v[t] > tau;
+            if (__any(any)) {
+#pragma unroll
+                for (int t = 0; t < SW_PRE; ++t) append(v[t] != 0.0 && v[t] > tau, v[t], (int)cur.ent[t].x);
+            }
+        } else if (__any(v[0] != 0.0 || v[1] != 0.0 || v[2] != 0.0)) {
+            // short list: a lower bound of the window's K-th best sum by a bit-by-bit search over the order-preserving
+            // high words of ALL claimed sums (ballot + popcount; excluded columns are looked up first)
+            uint32_t key[SW_PRE];
+#pragma unroll
+            for (int t = 0; t < SW_PRE; ++t) {
+                if (v[t] != 0.0 && n_ex != 0 && excluded((int)cur.ent[t].x)) v[t] = 0.0;
+                const uint32_t hi = (uint32_t)__double2hiint(v[t]);
+                key[t] = v[t] != 0.0 ? (hi ^ ((uint32_t)((int32_t)hi >> 31) | 0x80000000u)) : 0u;
+            }
+            uint32_t fl = 0;
+#pragma unroll
+            for (int b = 31; b > 31 - SD_FLOOR_BITS; --b) {
+                const uint32_t trial = fl | (1u << b);
+                int n_at = 0;
+#pragma unroll
+                for (int t = 0; t < SW_PRE; ++t) n_at += __popcll(__ballot(key[t] >= trial));
+                if (n_at >= K) fl = trial;
+            }
+            const uint32_t floor_k = max(fl, 1u);
+#pragma unroll
+            for (int t = 0; t < SW_PRE; ++t) append(key[t] >= floor_k, v[t], (int)cur.ent[t].x);
+        }
+        if (!over && nq > cnt && (!full || nq - cnt >= SD_LAZY + K || nq + 24 > SW_CAND)) merge();   // lazy, like the kernel above
+    };
+    static_assert(SW_PRE == 3, "the short-list vote names three sums");
+    for (int c = 0; c < n_win && !over; c += 2) {
+        window(c, A, B);
+        if (c + 1 < n_win && !over) window(c + 1, B, A);
+    }
+    if (!over && nq > cnt) merge();
+    // zero-sum columns (score 0 * col_scale) can still rank when the list is short or ends at or below zero: the sweep
+    // over them lives in the workgroup kernel
+    if (over || cnt < K || !(tau > 0.0)) { hand_over(); return; }
+    if (lane < K) {
+        out_ids[i * K + lane] = S.cc[lane];
+        out_scores[i * K + lane] = (float)ldexp(S.cv[lane], -p.fx_shift);
+    }
+}
+
+// entry offsets (from the row's first entry) of every row per SW_WIN-column window: [n_rows][n_win + 1]
+__global__ void build_win_ptr_kernel(const int64_t *cptr, int nc1, const int32_t *idx, int64_t n_rows, int n_win, uint32_t *cw)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_rows * (n_win + 1)) return;
+    const int64_t r = t / (n_win + 1);
+    const int c = (int)(t - r * (n_win + 1));
+    const int64_t b = cptr[r * nc1], e = cptr[r * nc1 + nc1 - 1];
+    int64_t lo = b, hi = e;
+    const int64_t target = (int64_t)c * SW_WIN;
+    while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (idx[mid] < target) lo = mid + 1; else hi = mid; }
+    cw[t] = (uint32_t)(lo - b);
+}
+
+int item_sparse_wave_windows(int n_items) { return (n_items + SW_WIN - 1) / SW_WIN; }
+
+int launch_build_win_ptr(const int64_t *cptr, int n_chunks, const int32_t *idx, int64_t n_rows, int n_win, uint32_t *cw, hipStream_t s)
+{
+    const int64_t total = n_rows * (n_win + 1);
+    if (total <= 0) return 0;
+    hipLaunchKernelGGL(build_win_ptr_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, cptr, n_chunks + 1, idx, n_rows, n_win, cw);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
 int item_sparse_read_phases(unsigned long long *out16)
@@ -978,10 +1228,22 @@ int launch_item_sparse_topk(const ItemItemParams &p, int32_t *out_ids, float *ou
     if (p.n <= 0 || p.n > (int64_t)0xffffffffu / SD_BLOCK || p.K < 1 || p.K > SD_MAXK) return -1;
     if (p.n_chunks < 1 || p.sp_cap < 2 * SD_MAXK || p.sp_cap > SD_CAND) return -1;
     // fewer than 2^30 entries (+ the over-read pad): 32-bit entry indices from the array bases (fewer address instructions)
-    if (p.m_nnz + II_CSR_PAD < ((int64_t)1 << 30))
-        hipLaunchKernelGGL(item_sparse_topk_kernel<true>, dim3((unsigned)p.n), dim3(SD_BLOCK), 0, stream, p, out_ids, out_scores);
+    const bool idx32 = p.m_nnz + II_CSR_PAD < ((int64_t)1 << 30);
+    if (p.cptr_w != nullptr && p.long_list != nullptr && idx32) {
+        // one wave per user; what that kernel hands over (long histories, lists that zero-sum columns may enter, mass
+        // ties) is ranked by the workgroup kernel in list mode -- a fixed-size grid that reads the count on the device
+        if (hipMemsetAsync(p.long_cnt, 0, sizeof(int), stream) != hipSuccess) return -3;
+        hipLaunchKernelGGL(item_sparse_wave_kernel, dim3((unsigned)((p.n + SW_WAVES - 1) / SW_WAVES)), dim3(64 * SW_WAVES), 0, stream, p, out_ids, out_scores);
+        const unsigned grid = (unsigned)(p.n < 2048 ? p.n : 2048);
+        hipLaunchKernelGGL((item_sparse_topk_kernel<true, true>), dim3(grid), dim3(SD_BLOCK), 0, stream, p, out_ids, out_scores);
+        return hipGetLastError() == hipSuccess ? 0 : -3;
+    }
+    ItemItemParams q = p;
+    q.long_list = nullptr; q.long_cnt = nullptr;             // direct mode: workgroup b ranks user b
+    if (idx32)
+        hipLaunchKernelGGL((item_sparse_topk_kernel<true, false>), dim3((unsigned)p.n), dim3(SD_BLOCK), 0, stream, q, out_ids, out_scores);
     else
-        hipLaunchKernelGGL(item_sparse_topk_kernel<false>, dim3((unsigned)p.n), dim3(SD_BLOCK), 0, stream, p, out_ids, out_scores);
+        hipLaunchKernelGGL((item_sparse_topk_kernel<false, false>), dim3((unsigned)p.n), dim3(SD_BLOCK), 0, stream, q, out_ids, out_scores);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 int item_sparse_pass_capacity() { return SD_CAND; }

@@ -82,22 +82,24 @@ def test_dense_topk_bit_exact_vs_oracle(torch, n_items, K, pen):
     np.testing.assert_array_equal(scores.cpu().numpy(), o_sc)
 
 
-@pytest.mark.parametrize("n_items,row_nnz,K,pen", [(3001, 40, 10, True), (10000, 120, 20, False), (20000, 300, 10, True)])
+@pytest.mark.parametrize("n_items,row_nnz,K,pen", [(3001, 40, 10, True), (10000, 120, 20, False), (20000, 300, 10, True), (9000, 12, 32, False)])
 def test_csr_topk_bit_exact_vs_oracle(torch, n_items, row_nnz, K, pen):
     w = _workload(50 + K, 301, n_items, 30, row_nnz=row_nnz, weights="prob", pen=pen)
     sc = _scorer(w)
     users = np.arange(w["n_users"], dtype=np.int32)
-    ids, scores = sc.rank_topk(users, K)
     o_ids, o_sc, _, _ = _oracle(w, sc, users, [K], K)
-    np.testing.assert_array_equal(ids.cpu().numpy(), o_ids)
-    np.testing.assert_array_equal(scores.cpu().numpy(), o_sc)
+    for wave in (1, 0):                         # the wave-per-user kernel (+ hand-over) and the workgroup-per-user kernel alone
+        sc.set_option("csr_wave", wave)
+        ids, scores = sc.rank_topk(users, K)
+        np.testing.assert_array_equal(ids.cpu().numpy(), o_ids)
+        np.testing.assert_array_equal(scores.cpu().numpy(), o_sc)
     # the library's shift follows the documented rule
     assert sc.item_fixed_point_shift() == orc.item_fixed_point_shift(w["csr"].data, w["h_ptr"], w["h_val"], w["csr"].indices,
                                                                    w["col_scale"])
 
 
-@pytest.mark.parametrize("pass_entries", [0, 64])
-def test_csr_topk_pass_shapes(torch, pass_entries):
+@pytest.mark.parametrize("pass_entries,wave", [(0, 1), (0, 0), (64, 0)])
+def test_csr_topk_pass_shapes(torch, pass_entries, wave):
     """The CSR top-K kernel over its paths: candidates ranked by counting and -- candidate buffer cut to 64 entries,
     which the first windows of these users overflow -- by the exact block-wide argmax rounds; histories longer than a
     staging round (128 rows), exclusion rows beyond the LDS copy (256 entries), negative values (zero-sum columns
@@ -106,6 +108,7 @@ def test_csr_topk_pass_shapes(torch, pass_entries):
     assert np.diff(w["h_ptr"]).max() > 256                                  # staging rounds and a global exclusion row
     w["csr"].data[::3] *= -1.0
     sc = _scorer(w)
+    sc.set_option("csr_wave", wave)            # 1: one wave per user, handing long histories / zero-sum lists to the workgroup kernel
     if pass_entries:
         sc.set_option("csr_cand_cap", pass_entries)
     users = np.r_[np.arange(w["n_users"]), [w["n_users"] + 5]].astype(np.int32)
@@ -117,6 +120,7 @@ def test_csr_topk_pass_shapes(torch, pass_entries):
     # all-negative model: every touched column loses against the untouched (zero-score) ones
     w["csr"].data[:] = -np.abs(w["csr"].data)
     sc = _scorer(w)
+    sc.set_option("csr_wave", wave)
     if pass_entries:
         sc.set_option("csr_cand_cap", pass_entries)
     ids, scores = sc.rank_topk(users, 10)

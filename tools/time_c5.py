@@ -15,6 +15,7 @@ caps = [int(a) for a in sys.argv[3].split(",")] if len(sys.argv) > 3 else [0]
 for dbg, cap in [(int(a), c) for a in (sys.argv[2].split(",") if len(sys.argv) > 2 else ["0"]) for c in caps]:
     sc.set_option("debug_mode", dbg)
     sc.set_option("csr_cand_cap", cap)
+    sc.set_option("csr_wave", int(sys.argv[5]) if len(sys.argv) > 5 else 1)
     for K in KS:
         sc.rank_topk(users, K); torch.cuda.synchronize()
         t = time.perf_counter()
