@@ -1117,6 +1117,10 @@ __global__ __launch_bounds__(64 * SW_WAVES, 4) void item_sparse_wave_kernel(Item
     int b1 = has_row ? (int)cw[1] : 0;
     uint32_t b2raw = cw[min(2, n_win)];
     issue(A, 0, b1);
+    // The common window -- the list is full and no claimed sum beats its K-th -- is kept to the loads, the adds, the
+    // exchanges and ONE vote; everything else (candidates, segments longer than the prefetch, the short list of the first
+    // window, merges) sits behind that vote.
+    double tau_eff = -INFINITY;                           // the K-th sum while the list is full, else -inf (every sum is a candidate)
     auto window = [&](int c, const Pre &cur, Pre &nxt) __attribute__((always_inline)) {
         const int colA = c * SW_WIN;
         const int b2 = has_row ? (int)b2raw : 0;
@@ -1124,28 +1128,31 @@ __global__ __launch_bounds__(64 * SW_WAVES, 4) void item_sparse_wave_kernel(Item
         b2raw = cw[min(c + 3, n_win)];
         consume(cur, colA);
         b1 = b2;
-        sw_lds_order();                                   // the window's sums are complete (all lanes' adds precede the exchanges)
-        const bool full = cnt == K;
+        // the window's sums are complete: the LDS performs one wave's operations in issue order, so the exchanges below
+        // find every lane's adds without waiting for them (only the compiler must keep the order)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
         double v[SW_PRE];
 #pragma unroll
         for (int t = 0; t < SW_PRE; ++t) {
             const bool ok = cur.first + t * L < cur.end;
             v[t] = claim(ok ? (int)cur.ent[t].x - colA : SW_WIN + lane);
         }
-        for (int q = cur.first + SW_PRE * L; __any(q < cur.end); q += L) {    // (rare; wave-uniform trip count for the ballots)
+        bool look = cur.first + SW_PRE * L < cur.end;     // a segment longer than the prefetch
+#pragma unroll
+        for (int t = 0; t < SW_PRE; ++t) look |= v[t] > tau_eff;
+        if (__builtin_expect(__any(look) == 0, 1)) return;
+        const bool full = cnt == K;
+        for (int q = cur.first + SW_PRE * L; __any(q < cur.end); q += L) {    // (wave-uniform trip count for the ballots)
             const bool in = q < cur.end;
             const int col = in ? (int)rp[base32 + (uint32_t)q].x : 0;
             const double vv = in ? claim(col - colA) : 0.0;
             append(in && vv != 0.0 && (!full || vv > tau), vv, col);
         }
         if (full) {
-            bool any = false;                             // (a zero passes when the K-th sum is negative: sorted out inside)
 #pragma unroll
-            for (int t = 0; t < SW_PRE; ++t) any |= v[t] > tau;
-            if (__any(any)) {
-#pragma unroll
-                for (int t = 0; t < SW_PRE; ++t) append(v[t] != 0.0 && v[t] > tau, v[t], (int)cur.ent[t].x);
-            }
+            for (int t = 0; t < SW_PRE; ++t) append(v[t] != 0.0 && v[t] > tau, v[t], (int)cur.ent[t].x);   // (a zero passes the vote when the K-th sum is negative)
         } else if (__any(v[0] != 0.0 || v[1] != 0.0 || v[2] != 0.0)) {
             // short list: a lower bound of the window's K-th best sum by a bit-by-bit search over the order-preserving
             // high words of ALL claimed sums (ballot + popcount; excluded columns are looked up first)
@@ -1170,6 +1177,7 @@ __global__ __launch_bounds__(64 * SW_WAVES, 4) void item_sparse_wave_kernel(Item
             for (int t = 0; t < SW_PRE; ++t) append(key[t] >= floor_k, v[t], (int)cur.ent[t].x);
         }
         if (!over && nq > cnt && (!full || nq - cnt >= SD_LAZY + K || nq + 24 > SW_CAND)) merge();   // lazy, like the kernel above
+        tau_eff = cnt == K ? tau : -INFINITY;
     };
     static_assert(SW_PRE == 3, "the short-list vote names three sums");
     for (int c = 0; c < n_win && !over; c += 2) {

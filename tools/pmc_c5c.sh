@@ -10,8 +10,9 @@ import csv, glob
 for f in sorted(glob.glob("$OUT/*/*/*_counter_collection.csv")):
     acc = {}
     for row in csv.DictReader(open(f)):
-        if "item_sparse_topk" in row["Kernel_Name"]:
-            acc.setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
-    for k, v in acc.items():
-        print(k, sum(v) / 4 / 262144, "per user (4 launches of 262144 users)")
+        if "item_sparse" in row["Kernel_Name"]:
+            kn = "wave" if "wave" in row["Kernel_Name"] else "workgroup"
+            acc.setdefault((kn, row["Counter_Name"]), []).append(float(row["Counter_Value"]))
+    for (kn, k), v in sorted(acc.items()):
+        print(kn, k, sum(v) / 4 / 262144, "per user of the launch (4 launches of 262144 users)")
 PY
