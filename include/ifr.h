@@ -220,6 +220,14 @@ int ifr_rank_topk(ifr_handle h, const int32_t *user_ids, int64_t n, int K,
 int ifr_rank_topk_dense(ifr_handle h, const int32_t *user_ids, int64_t n, int K, int32_t *out_ids,
                         float *out_scores, float *dense_out, int64_t ld, void *stream);
 
+/* ifr_rank_topk_dense for a float64 dense item matrix (ifr_set_item_matrix_dense_f64 / option "item_f64"): the lists
+ * are ranked on the float64 sums like ifr_rank_topk does, and the same sums are written as float64 rows (what
+ * ifr_score_dense_f64 returns) -- one pass over the matrix for the top-K metrics and for AUC (recom_ease.py:123-124 ->
+ * recommender.py:643-661).  K <= IFR_MAX_TOPK_ITEM, ld >= n_items.  (ifr_rank_topk_dense itself serves a dense fp32
+ * item matrix the same way, with fp32 rows.) */
+int ifr_rank_topk_dense_f64(ifr_handle h, const int32_t *user_ids, int64_t n, int K, int32_t *out_ids, float *out_scores,
+                            double *dense_out, int64_t ld, void *stream);
+
 /* ifr_rank_topk for callers that cannot allocate: code under HIP graph capture, tight serving loops, harnesses that
  * forbid hipMalloc.  (No counterpart in the reference.)  Same arguments, same results bit for bit as ifr_rank_topk for
  * a dot-product model (IFR_ERR_STATE otherwise), but the call makes no hipMalloc / hipFree / allocating library call:

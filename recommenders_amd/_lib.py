@@ -57,6 +57,7 @@ SIGNATURES = {
     "ifr_rank_topk": (ctypes.c_int, [vp, vp, ctypes.c_int64, ctypes.c_int, vp, vp, vp]),
     "ifr_rank_topk_noalloc": (ctypes.c_int, [vp, vp, ctypes.c_int64, ctypes.c_int, vp, vp, vp]),
     "ifr_rank_topk_dense": (ctypes.c_int, [vp, vp, ctypes.c_int64, ctypes.c_int, vp, vp, vp, ctypes.c_int64, vp]),
+    "ifr_rank_topk_dense_f64": (ctypes.c_int, [vp, vp, ctypes.c_int64, ctypes.c_int, vp, vp, vp, ctypes.c_int64, vp]),
     "ifr_eval_topk_metrics": (ctypes.c_int, [vp, vp, ctypes.c_int64, vp, ctypes.c_int, c_i32p, ctypes.c_int,
                                              vp, vp, vp, vp]),
     "ifr_eval_ranked_metrics": (ctypes.c_int, [vp, vp, ctypes.c_int64, vp, ctypes.c_int64, vp, c_i32p, ctypes.c_int,

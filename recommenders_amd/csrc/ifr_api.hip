@@ -954,12 +954,18 @@ static int prof_end(ifr_handle h, hipStream_t s, const std::pair<hipEvent_t, hip
     return IFR_OK;
 }
 
+// dense / dense_ld: the same launch also writes every score (dense item matrices: fp32 rows, or the float64 sums of the
+// fp64 option) -- one scoring pass for the lists and for the row consumers (AUC)
 static int rank_topk_item_item(ifr_handle h, const int32_t *user_ids, int64_t n, int K, int KL, int32_t *out_ids,
-                               float *out_scores, hipStream_t s)
+                               float *out_scores, hipStream_t s, void *dense = nullptr, int64_t dense_ld = 0)
 {
     ifr::ItemItemParams p;
     int rc = item_item_params(h, user_ids, n, &p);
     if (rc) return rc;
+    if (dense) {
+        if (h->iiM64) p.out64 = (double *)dense; else p.out = (float *)dense;
+        p.ld = dense_ld;
+    }
     if (n > (int64_t)1 << 24) return fail(h, IFR_ERR_ARG, "ifr_rank_topk: more than 2^24 users in one call, split the user list");
     p.K = K; p.KL = KL;
     std::pair<hipEvent_t, hipEvent_t> ev;
@@ -1033,8 +1039,16 @@ int ifr_rank_topk_dense(ifr_handle h, const int32_t *user_ids, int64_t n, int K,
                         float *dense_out, int64_t ld, void *stream)
 {
     if (!h) return IFR_ERR_ARG;
+    if (h->mode == MODE_ITEM_DENSE && !h->iiM64) {              // dense fp32 item matrix: lists + rows from one pass over M
+        if (n == 0) return IFR_OK;
+        if (!user_ids || !out_ids || !out_scores || !dense_out || n < 0) return fail(h, IFR_ERR_ARG, "ifr_rank_topk_dense: null/negative argument");
+        if (K < 1 || K > IFR_MAX_TOPK_ITEM) return fail(h, IFR_ERR_ARG, "ifr_rank_topk_dense: K must be in [1, 32] for an item-item model");
+        if (ld < h->n_items) return fail(h, IFR_ERR_ARG, "ifr_rank_topk_dense: ld < n_items");
+        IFR_HIP(h, hipSetDevice(h->device));
+        return rank_topk_item_item(h, user_ids, n, K, K <= 16 ? 16 : 32, out_ids, out_scores, (hipStream_t)stream, dense_out, ld);
+    }
     if (h->mode != MODE_FACTOR)
-        return fail(h, IFR_ERR_STATE, "ifr_rank_topk_dense: needs a dot-product model (ifr_set_factors); use ifr_rank_topk + ifr_score_dense");
+        return fail(h, IFR_ERR_STATE, "ifr_rank_topk_dense: needs a dot-product model or a dense fp32 item matrix (fp64: ifr_rank_topk_dense_f64; CSR: ifr_rank_topk + ifr_score_dense_f64)");
     if (n == 0) return IFR_OK;
     if (!user_ids || !out_ids || !out_scores || !dense_out || n < 0) return fail(h, IFR_ERR_ARG, "ifr_rank_topk_dense: null/negative argument");
     if (K < 1 || K > IFR_MAX_TOPK) return fail(h, IFR_ERR_ARG, "ifr_rank_topk_dense: K must be in [1, 128]");
@@ -1043,6 +1057,19 @@ int ifr_rank_topk_dense(ifr_handle h, const int32_t *user_ids, int64_t n, int K,
     IFR_HIP(h, hipSetDevice(h->device));
     if (K > std::min(h->opt_pair_max, h->pair_limit) || (K > 16 && !h->opt_pair_topk)) return rank_topk_wide(h, user_ids, n, K, out_ids, out_scores, dense_out, ld, (hipStream_t)stream);
     return rank_topk_factor(h, user_ids, n, K, 16, out_ids, out_scores, dense_out, ld, (hipStream_t)stream);
+}
+
+int ifr_rank_topk_dense_f64(ifr_handle h, const int32_t *user_ids, int64_t n, int K, int32_t *out_ids, float *out_scores,
+                            double *dense_out, int64_t ld, void *stream)
+{
+    if (!h) return IFR_ERR_ARG;
+    if (h->mode != MODE_ITEM_DENSE || !h->iiM64) return fail(h, IFR_ERR_STATE, "ifr_rank_topk_dense_f64: needs a float64 dense item matrix");
+    if (n == 0) return IFR_OK;
+    if (!user_ids || !out_ids || !out_scores || !dense_out || n < 0) return fail(h, IFR_ERR_ARG, "ifr_rank_topk_dense_f64: null/negative argument");
+    if (K < 1 || K > IFR_MAX_TOPK_ITEM) return fail(h, IFR_ERR_ARG, "ifr_rank_topk_dense_f64: K must be in [1, 32]");
+    if (ld < h->n_items) return fail(h, IFR_ERR_ARG, "ifr_rank_topk_dense_f64: ld < n_items");
+    IFR_HIP(h, hipSetDevice(h->device));
+    return rank_topk_item_item(h, user_ids, n, K, K <= 16 ? 16 : 32, out_ids, out_scores, (hipStream_t)stream, dense_out, ld);
 }
 
 static int redo_from_dense_rows(ifr_handle h, const int32_t *user_ids, const int32_t *overflow_slots, uint32_t n_over, int K,

@@ -175,7 +175,7 @@ __global__ __launch_bounds__(II_BLOCK, 3) void item_item_kernel(ItemItemParams p
                     const int col = col0 + q * II_PASS + v;
                     double s = a64[q][v];
                     if (p.pen != nullptr) s *= (double)p.pen[col];
-                    if (!TOPK && p.out64 != nullptr && col < p.n_items) p.out64[i * p.ld + col] = s;
+                    if (p.out64 != nullptr && col < p.n_items) p.out64[i * p.ld + col] = s;      // (TOPK: the rows as well, one scoring pass for both)
                     a64[q][v] = s;
                     acc[q][v] = (float)s;
                 }
@@ -327,7 +327,7 @@ __global__ __launch_bounds__(II_BLOCK, 3) void item_item_kernel(ItemItemParams p
         }
     }
 
-    if (!TOPK) {
+    if (!TOPK || (!SPARSE && !F64 && p.out != nullptr)) {      // dense rows; in a TOPK launch: as well as the lists (one scoring pass)
 #pragma unroll
         for (int q = 0; q < PASSES; ++q) {
 #pragma unroll
@@ -336,7 +336,7 @@ __global__ __launch_bounds__(II_BLOCK, 3) void item_item_kernel(ItemItemParams p
                 if (col < p.n_items) p.out[i * p.ld + col] = acc[q][v];
             }
         }
-        return;
+        if (!TOPK) return;
     }
 
     // ---- exclusion bitmap of this chunk (bit set = not a candidate), then scores -> LDS

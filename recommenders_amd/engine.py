@@ -401,28 +401,35 @@ class HipScorer:
     MAX_TOPK_WITH_DENSE = 128     # ifr_rank_topk_dense (= IFR_MAX_TOPK)
 
     def can_rank_topk_dense(self, K):
-        """True when rank_topk_dense serves this model and cut-off in one kernel (dot-product model, K <= 128, no
-        unknown catalogue items to pad)."""
-        return self.item_model is None and 1 <= int(K) <= self.MAX_TOPK_WITH_DENSE and \
-            max(getattr(self, "catalogue_items", 0), self.n_items) == self.n_items
+        """True when rank_topk_dense serves this model and cut-off in one kernel: a dot-product model (K <= 128) or a
+        dense item matrix, fp32 or float64 (K <= 32), and no unknown catalogue items to pad."""
+        if max(getattr(self, "catalogue_items", 0), self.n_items) != self.n_items:
+            return False
+        if self.item_model is None:
+            return 1 <= int(K) <= self.MAX_TOPK_WITH_DENSE
+        return self.item_model == "dense" and 1 <= int(K) <= 32
 
     def rank_topk_dense(self, user_ids, K, dense=None, out_ids=None, out_scores=None):
-        """rank_topk and score_dense in one launch (one GEMM instead of two): returns (ids [n,K], scores [n,K],
-        dense [n, n_items] view).  The dense buffer has rows of n_items rounded up to 32 floats."""
+        """rank_topk and the score rows in one launch (one scoring pass instead of two): returns (ids [n,K], scores
+        [n,K], dense [n, n_items] view).  Rows are fp32 with n_items rounded up to 32 columns, or -- a float64 dense item
+        matrix -- the float64 sums (what score_rows returns), columns rounded up to 4."""
         torch = _torch()
         u = self._dev_users(user_ids)
         n = u.numel()
-        ld = (self.n_items + 31) // 32 * 32
+        f64 = self.item_model == "dense" and self.rows_are_f64()
+        ld = (self.n_items + 3) // 4 * 4 if f64 else (self.n_items + 31) // 32 * 32
+        dt = torch.float64 if f64 else torch.float32
         if dense is None:
-            dense = torch.empty((n, ld), dtype=torch.float32, device=self.device)
-        if dense.dim() != 2 or dense.shape[0] < n or dense.shape[1] < ld or dense.stride(1) != 1 or dense.dtype != torch.float32:
-            raise ValueError(f"rank_topk_dense: dense must be float32 [>= {n}, >= {ld}] with unit column stride")
+            dense = torch.empty((n, ld), dtype=dt, device=self.device)
+        if dense.dim() != 2 or dense.shape[0] < n or dense.shape[1] < ld or dense.stride(1) != 1 or dense.dtype != dt:
+            raise ValueError(f"rank_topk_dense: dense must be {dt} [>= {n}, >= {ld}] with unit column stride")
         if out_ids is None:
             out_ids = torch.empty((n, K), dtype=torch.int32, device=self.device)
         if out_scores is None:
             out_scores = torch.empty((n, K), dtype=torch.float32, device=self.device)
-        self._check(self._lib.ifr_rank_topk_dense(self._h, u.data_ptr(), n, int(K), out_ids.data_ptr(), out_scores.data_ptr(),
-                                                  dense.data_ptr(), dense.stride(0), self._stream()))
+        fn = self._lib.ifr_rank_topk_dense_f64 if f64 else self._lib.ifr_rank_topk_dense
+        self._check(fn(self._h, u.data_ptr(), n, int(K), out_ids.data_ptr(), out_scores.data_ptr(),
+                       dense.data_ptr(), dense.stride(0), self._stream()))
         return out_ids, out_scores, dense[:n, : self.n_items]
 
     def select_topk(self, user_ids, scores, K, out_ids=None, out_scores=None):

@@ -717,9 +717,10 @@ def ranking_eval(model, metrics, train_set, test_set, val_set=None, rating_thres
             kmax = max(ks)
             if fused_dense:
                 ld = (n_items + 31) // 32 * 32
-                step = _rows_that_fit(eng, min(n, int((batch_pairs or 1 << 32) // ld)), 4 * ld)
+                bpi = eng.row_bytes_per_item() if hasattr(eng, "row_bytes_per_item") else 4     # 8: a float64 item matrix
+                step = _rows_that_fit(eng, min(n, int((batch_pairs or 1 << 32) // ld)), bpi * ld)
                 ids = torch.empty((n, kmax), dtype=torch.int32, device=eng.device)
-                rows = torch.empty((step, ld), dtype=torch.float32, device=eng.device)
+                rows = torch.empty((step, ld), dtype=torch.float64 if bpi == 8 else torch.float32, device=eng.device)
                 auc = np.empty(n)
                 for b in range(0, n, step):
                     bu = dev_users[b:b + step]

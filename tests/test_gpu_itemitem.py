@@ -275,6 +275,31 @@ def test_facade_matches_reference(torch, gap, name, form):
         assert len(ranked) == d[f"{name}__n_cand"][r]
 
 
+@pytest.mark.parametrize("precision", ["f32", "f64"])
+def test_dense_item_matrix_lists_and_rows_in_one_launch(torch, precision):
+    """ifr_rank_topk_dense / ifr_rank_topk_dense_f64 for a dense item matrix: the lists of ifr_rank_topk and the rows of
+    ifr_score_dense / ifr_score_dense_f64 from ONE pass over M (what ranking_eval uses for top-K cut-offs + AUC)."""
+    from recommenders_amd import HipScorer
+    w = _workload(91, 257, 9001, 22, pen=True)
+    sc = HipScorer(0)
+    sc.set_item_matrix_dense(w["M"].astype(np.float64) if precision == "f64" else w["M"], w["col_scale"], precision=precision)
+    sc.set_history_csr(w["h_ptr"], w["h_idx"], w["h_val"])
+    sc.set_exclusion_csr(w["excl_ptr"], w["excl_idx"])
+    sc.set_truth_csr(w["truth_ptr"], w["truth_idx"])
+    users = np.r_[np.arange(w["n_users"]), [w["n_users"] + 2]].astype(np.int32)[::-1].copy()
+    assert sc.can_rank_topk_dense(32) and not sc.can_rank_topk_dense(33)
+    for K in (10, 32):
+        ids, scores = sc.rank_topk(users, K)
+        ids2, scores2, dense = sc.rank_topk_dense(users, K)
+        np.testing.assert_array_equal(ids2.cpu().numpy(), ids.cpu().numpy())
+        np.testing.assert_array_equal(scores2.cpu().numpy(), scores.cpu().numpy())
+        rows = sc.score_rows(users)
+        assert dense.dtype == rows.dtype == (torch.float64 if precision == "f64" else torch.float32)
+        np.testing.assert_array_equal(dense.cpu().numpy(), rows[:, : w["n_items"]].cpu().numpy())
+        np.testing.assert_array_equal(sc.auc_dense(users, dense).cpu().numpy(), sc.auc_dense(users, rows).cpu().numpy())
+    sc.close()
+
+
 @pytest.mark.parametrize("form", ["dense", "csr"])
 def test_item_item_cutoff_beyond_32_through_partial_ranking(torch, form):
     """rank_topk(K = 50) of an item-item model: dense rows (ifr_score_dense) + ifr_select_topk, against the oracle."""
