@@ -1153,7 +1153,10 @@ __global__ __launch_bounds__(64 * SW_WAVES, 4) void item_sparse_wave_kernel(Item
         if (full) {
 #pragma unroll
             for (int t = 0; t < SW_PRE; ++t) append(v[t] != 0.0 && v[t] > tau, v[t], (int)cur.ent[t].x);   // (a zero passes the vote when the K-th sum is negative)
-        } else if (__any(v[0] != 0.0 || v[1] != 0.0 || v[2] != 0.0)) {
+        } else if ([&]() { bool nz = false;
+#pragma unroll
+                           for (int t = 0; t < SW_PRE; ++t) nz |= v[t] != 0.0;
+                           return __any(nz) != 0; }()) {
             // short list: a lower bound of the window's K-th best sum by a bit-by-bit search over the order-preserving
             // high words of ALL claimed sums (ballot + popcount; excluded columns are looked up first)
             uint32_t key[SW_PRE];
@@ -1179,7 +1182,6 @@ __global__ __launch_bounds__(64 * SW_WAVES, 4) void item_sparse_wave_kernel(Item
         if (!over && nq > cnt && (!full || nq - cnt >= SD_LAZY + K || nq + 24 > SW_CAND)) merge();   // lazy, like the kernel above
         tau_eff = cnt == K ? tau : -INFINITY;
     };
-    static_assert(SW_PRE == 3, "the short-list vote names three sums");
     for (int c = 0; c < n_win && !over; c += 2) {
         window(c, A, B);
         if (c + 1 < n_win && !over) window(c + 1, B, A);

@@ -53,6 +53,8 @@ for case in range(cases):
     sc.set_truth_csr(np.zeros(n_users + 1, np.int64), np.zeros(0, np.int32))
     if form == "csr" and rng.integers(2):
         sc.set_option("csr_cand_cap", int(rng.choice([64, 100, 256])))
+    if form == "csr":
+        sc.set_option("csr_wave", int(rng.integers(2)))                 # the wave-per-user kernel (+ hand-over), or the workgroup kernel alone
     t = time.perf_counter()
     ids, scores = sc.rank_topk(users, K)
     ids, scores = ids.cpu().numpy(), scores.cpu().numpy()
@@ -70,12 +72,16 @@ for case in range(cases):
                 ex = e_idx[e_ptr[u]:e_ptr[u + 1]]
             else:
                 o32, ex = np.zeros(n_items, np.float32) * (1.0 if col_scale is None else col_scale), np.zeros(0, np.int32)
+            if u >= n_users:
+                o64 = o32.astype(np.float64)
             keep = ~np.isnan(o32)
             ok &= np.array_equal(rows32[i], o32, equal_nan=True)
-            o32c = np.where(keep, o32, -np.inf)
-            # NaN scores never rank (dropped like exclusions)
-            ex2 = np.union1d(ex, np.flatnonzero(~keep)).astype(np.int32)
-            oi, os_, _ = orc.c_rank_topk(o32c, ex2, K)
+            # the float64 sums are what is ranked (canonical order: sum descending, item ascending); NaN scores never
+            # rank (dropped like exclusions); the list's scores are the winners rounded to fp32
+            cand = np.setdiff1d(np.flatnonzero(keep), ex).astype(np.int64)
+            head = orc.canonical_rank(cand, (o64[cand] + 0.0), K)
+            oi = np.full(K, -1, np.int32); oi[: len(head)] = head
+            os_ = np.full(K, -np.inf, np.float32); os_[: len(head)] = o64[head].astype(np.float32)
             ok &= np.array_equal(ids[i], oi) and np.array_equal(scores[i], os_)
     else:
         shift = sc.item_fixed_point_shift() if form == "csr" else 0
