@@ -411,3 +411,40 @@ def test_user_results_reads_and_pickles_like_the_reference_dict():
     back = pickle.loads(pickle.dumps(r))
     assert type(back) is dict and back == r.to_dict()
     assert r == pytest.approx({2: 0.2, 5: 0.5, 7: 0.7 + 1e-15})
+
+
+def test_user_results_over_values_that_are_still_elsewhere():
+    """ranking_eval hands `user_results` a reader for per-user values that are still on the device: nothing is copied
+    until a value is read, then once; unsorted users materialise at once (the order has to be fixed)."""
+    from recommenders_amd import UserResults
+    calls = []
+
+    def read():
+        calls.append(1)
+        return np.array([0.25, 0.5, 0.75])
+    r = UserResults([3, 8, 9], read)
+    assert len(r) == 3 and 8 in r and list(r) == [3, 8, 9] and not calls          # keys need no values
+    assert r[8] == 0.5 and r.values() == [0.25, 0.5, 0.75] and r == {3: 0.25, 8: 0.5, 9: 0.75}
+    assert len(calls) == 1
+    r2 = UserResults([9, 3, 8], lambda: np.array([0.75, 0.25, 0.5]))
+    assert r2 == r and r2.keys() == [3, 8, 9]
+
+
+def test_device_eval_csrs_fall_back_to_the_host_build_without_an_engine(toy):
+    """The object that stands for device-built candidate sets: its SciPy forms come from the engine that holds them or,
+    when that engine is gone and the splits are SciPy matrices, from the host build -- the same rows either way."""
+    d = toy
+    train, test, val = _csr(d, "train"), _csr(d, "test"), _csr(d, "val")
+    n_items, thr = int(d["num_items"]), float(d["rating_threshold"])
+    n_rows = int(np.flatnonzero(np.diff(test.indptr)).max()) + 1
+    obj = ifr_eval.DeviceEvalCsrs((train, test, val), thr, n_items, n_rows, 0)
+    truth, excl, _ = ifr_eval.build_eval_csrs(train, test, val, thr, n_items, n_rows)
+    for which, ref in (("truth", truth), ("exclusion", excl)):
+        got = obj.host(which)
+        assert (got != ref).nnz == 0 and got.shape == ref.shape
+    # memoised per splits like the host CSRs, and keyed on content
+    ifr_eval.clear_eval_cache()
+    a = ifr_eval.cached_device_eval_csrs(train, test, val, thr, n_items, n_rows)
+    assert ifr_eval.cached_device_eval_csrs(train, test, val, thr, n_items, n_rows) is a
+    assert ifr_eval.cached_device_eval_csrs(train, test, val, thr + 1, n_items, n_rows) is not a
+    ifr_eval.clear_eval_cache()
