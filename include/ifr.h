@@ -56,8 +56,11 @@ const char *ifr_last_error(ifr_handle h);
  * ("pair_max": largest K of the pair path, default 100, at most 128);
  * "wide_chunk_cap", "wide_stats": tuning / statistics of that path; "item_f64": see ifr_fit_ease (none of these
  * changes a result);
- * "csr_wave": 0 = CSR top-K by the workgroup-per-user kernel only (default 1: one wave per user where the history
- * has at most 64 rows, the rest handed to that kernel; same results);
+ * "csr_wave": CSR top-K kernel choice -- 0 = the workgroup-per-user kernel only; 1 (default) = one wave per user where
+ * the history has at most 64 rows (the rest handed to the workgroup kernel), IF at most 1 % of the matrix's (row,
+ * 1024-column window) segments hold more than the three entries that kernel prefetches (measured when the matrix is
+ * set: evenly spread rows; on matrices with uniformly drawn columns the workgroup kernel is the faster one); 2 = force
+ * the wave kernel (tests).  Same results either way;
  * "csr_cand_cap": candidate buffer entries of the CSR top-K kernel (64 ... 256, 0 = default 256; tests shrink it to
  * force the overflow path; no result changes);
  * "debug_mode": development ablations (results may change; the fused kernel's modes, bits 0-2

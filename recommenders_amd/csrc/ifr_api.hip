@@ -82,6 +82,7 @@ struct ifr_handle_s {
     int opt_item_f64 = 0;        // ifr_fit_ease installs B in fp64
     int64_t *ii_cptr = nullptr; int32_t *ii_idx = nullptr; float *ii_val = nullptr; int64_t ii_nnz = 0;
     uint2 *ii_pair = nullptr;    // CSR entries as interleaved (column, value) pairs: what the CSR top-K kernel streams
+    double ii_long_frac = 0.0;   // share of (row, 1024-column window) segments longer than that kernel's prefetch
     uint32_t *ii_cptr_w = nullptr; int ii_n_win = 0;   // entry offsets per 1024-column window (wave-per-user CSR top-K kernel), or null
     void *ws_long = nullptr; size_t ws_long_bytes = 0;  // users that kernel hands over: [0] = count, then the list
     int opt_csr_wave = 1;        // 0: CSR top-K by the workgroup-per-user kernel only
@@ -424,7 +425,7 @@ int ifr_set_option(ifr_handle h, const char *name, int64_t value)
 #endif
         h->opt_debug = (int)value;
     }
-    else if (!strcmp(name, "csr_wave")) h->opt_csr_wave = value != 0;
+    else if (!strcmp(name, "csr_wave")) h->opt_csr_wave = value <= 0 ? 0 : (value == 1 ? 1 : 2);
     else if (!strcmp(name, "csr_cand_cap")) h->opt_csr_pass = value <= 0 ? 0 : (int)std::max<int64_t>(ifr::item_sparse_min_capacity(), std::min<int64_t>(value, ifr::item_sparse_pass_capacity()));
     else if (!strcmp(name, "catalogue_items")) {
         if (value != 0 && (value < h->n_items || value > (int64_t)1 << 30))
@@ -803,6 +804,16 @@ int ifr_set_item_matrix_csr(ifr_handle h, const int64_t *indptr, const int32_t *
                 hipMalloc((void **)&h->ii_cptr_w, wbytes) == hipSuccess) {
                 h->ii_n_win = n_win;
                 lrc = ifr::launch_build_win_ptr(h->ii_cptr, n_chunks, h->ii_idx, n_items, n_win, h->ii_cptr_w, 0);
+                // The wave-per-user kernel prefetches three entries per row and window and walks longer segments one load
+                // at a time: it only pays on matrices whose rows spread evenly over the windows (C5's synthetic W; with
+                // uniformly drawn columns 16 % of the segments are longer and it loses to the workgroup kernel).  More
+                // than 1 % long segments: the workgroup kernel serves every user (unless option csr_wave = 2 forces it).
+                unsigned long long *d_long = nullptr, n_long = 0;
+                if (!lrc && (hipMalloc((void **)&d_long, sizeof(n_long)) != hipSuccess || hipMemset(d_long, 0, sizeof(n_long)) != hipSuccess)) lrc = -4;
+                if (!lrc) lrc = ifr::launch_count_long_segments(h->ii_cptr_w, n_items, n_win, d_long, 0);
+                if (!lrc && hipMemcpy(&n_long, d_long, sizeof(n_long), hipMemcpyDeviceToHost) != hipSuccess) lrc = -3;
+                dfree(d_long);
+                h->ii_long_frac = (double)n_long / std::max<double>(1.0, (double)n_items * n_win);
             }
         }
     }
@@ -970,7 +981,7 @@ static int rank_topk_item_item(ifr_handle h, const int32_t *user_ids, int64_t n,
     p.K = K; p.KL = KL;
     std::pair<hipEvent_t, hipEvent_t> ev;
     if (h->mode == MODE_ITEM_CSR) {                  // one workgroup per user, final lists written directly
-        if (h->ii_cptr_w != nullptr && h->opt_csr_wave) {
+        if (h->ii_cptr_w != nullptr && (h->opt_csr_wave == 2 || (h->opt_csr_wave == 1 && h->ii_long_frac <= 0.01))) {
             rc = grow(h, &h->ws_long, &h->ws_long_bytes, sizeof(int32_t) * ((size_t)n + 1));
             if (rc) return rc;
             p.cptr_w = h->ii_cptr_w; p.n_win = h->ii_n_win;

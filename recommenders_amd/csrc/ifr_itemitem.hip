@@ -1210,6 +1210,30 @@ __global__ void build_win_ptr_kernel(const int64_t *cptr, int nc1, const int32_t
     cw[t] = (uint32_t)(lo - b);
 }
 
+// (row, window) segments with more entries than a lane prefetches: the wave-per-user kernel walks those one load at a
+// time, so it only pays on matrices whose rows spread evenly over the windows
+__global__ void count_long_segments_kernel(const uint32_t *cw, int64_t n_rows, int n_win, unsigned long long *count)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool is_long = false;
+    if (t < n_rows * n_win) {
+        const int64_t r = t / n_win;
+        const int c = (int)(t - r * n_win);
+        const uint32_t *row = cw + r * (n_win + 1);
+        is_long = row[c + 1] - row[c] > (uint32_t)SW_PRE;
+    }
+    const unsigned long long b = __ballot(is_long);
+    if ((threadIdx.x & 63) == 0 && b != 0ull) atomicAdd(count, (unsigned long long)__popcll(b));
+}
+
+int launch_count_long_segments(const uint32_t *cw, int64_t n_rows, int n_win, unsigned long long *count, hipStream_t s)
+{
+    const int64_t total = n_rows * n_win;
+    if (total <= 0) return 0;
+    hipLaunchKernelGGL(count_long_segments_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, cw, n_rows, n_win, count);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
 int item_sparse_wave_windows(int n_items) { return (n_items + SW_WIN - 1) / SW_WIN; }
 
 int launch_build_win_ptr(const int64_t *cptr, int n_chunks, const int32_t *idx, int64_t n_rows, int n_win, uint32_t *cw, hipStream_t s)

@@ -71,7 +71,7 @@ def test_c4_shape_dense_50000_items_bit_exact(torch):
     del B
 
 
-@pytest.mark.parametrize("cand_cap,wave", [(0, 1), (0, 0), (64, 0)])
+@pytest.mark.parametrize("cand_cap,wave", [(0, 1), (0, 2), (0, 0), (64, 0)])
 def test_c5_shape_csr_125000_items_256_neighbours_bit_exact(torch, cand_cap, wave):
     """31 windows per user; a user with 400 history rows (staging rounds, ~3 300 entries per window, an exclusion row
     beyond the LDS copy), one with 200 rows (one lane per row, segments longer than the prefetch), a single-row user, a
@@ -93,7 +93,7 @@ def test_c5_shape_csr_125000_items_256_neighbours_bit_exact(torch, cand_cap, wav
     sc.set_history_csr(h_ptr, h_idx, h_val)
     sc.set_exclusion_csr(h_ptr, h_idx)
     sc.set_truth_csr(t_ptr, t_idx)
-    sc.set_option("csr_wave", wave)             # 1: one wave per user (histories <= 64 rows), the rest handed to the workgroup kernel
+    sc.set_option("csr_wave", wave)             # 1 / 2: one wave per user (histories <= 64 rows; 2 = whatever the matrix looks like), the rest handed over
     if cand_cap:
         sc.set_option("csr_cand_cap", cand_cap)
     users = np.r_[np.arange(len(lengths)), [len(lengths) + 9]].astype(np.int32)

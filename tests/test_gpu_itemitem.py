@@ -88,7 +88,7 @@ def test_csr_topk_bit_exact_vs_oracle(torch, n_items, row_nnz, K, pen):
     sc = _scorer(w)
     users = np.arange(w["n_users"], dtype=np.int32)
     o_ids, o_sc, _, _ = _oracle(w, sc, users, [K], K)
-    for wave in (1, 0):                         # the wave-per-user kernel (+ hand-over) and the workgroup-per-user kernel alone
+    for wave in (2, 0):                         # the wave-per-user kernel forced (+ hand-over), and the workgroup-per-user kernel alone
         sc.set_option("csr_wave", wave)
         ids, scores = sc.rank_topk(users, K)
         np.testing.assert_array_equal(ids.cpu().numpy(), o_ids)
@@ -98,7 +98,7 @@ def test_csr_topk_bit_exact_vs_oracle(torch, n_items, row_nnz, K, pen):
                                                                    w["col_scale"])
 
 
-@pytest.mark.parametrize("pass_entries,wave", [(0, 1), (0, 0), (64, 0)])
+@pytest.mark.parametrize("pass_entries,wave", [(0, 2), (0, 0), (64, 0)])
 def test_csr_topk_pass_shapes(torch, pass_entries, wave):
     """The CSR top-K kernel over its paths: candidates ranked by counting and -- candidate buffer cut to 64 entries,
     which the first windows of these users overflow -- by the exact block-wide argmax rounds; histories longer than a
@@ -108,7 +108,7 @@ def test_csr_topk_pass_shapes(torch, pass_entries, wave):
     assert np.diff(w["h_ptr"]).max() > 256                                  # staging rounds and a global exclusion row
     w["csr"].data[::3] *= -1.0
     sc = _scorer(w)
-    sc.set_option("csr_wave", wave)            # 1: one wave per user, handing long histories / zero-sum lists to the workgroup kernel
+    sc.set_option("csr_wave", wave)            # 2: one wave per user (forced), handing long histories / zero-sum lists to the workgroup kernel
     if pass_entries:
         sc.set_option("csr_cand_cap", pass_entries)
     users = np.r_[np.arange(w["n_users"]), [w["n_users"] + 5]].astype(np.int32)

@@ -54,7 +54,7 @@ for case in range(cases):
     if form == "csr" and rng.integers(2):
         sc.set_option("csr_cand_cap", int(rng.choice([64, 100, 256])))
     if form == "csr":
-        sc.set_option("csr_wave", int(rng.integers(2)))                 # the wave-per-user kernel (+ hand-over), or the workgroup kernel alone
+        sc.set_option("csr_wave", int(rng.choice([0, 2])))              # the wave-per-user kernel forced (+ hand-over), or the workgroup kernel alone
     t = time.perf_counter()
     ids, scores = sc.rank_topk(users, K)
     ids, scores = ids.cpu().numpy(), scores.cpu().numpy()
