@@ -53,7 +53,8 @@ const char *ifr_last_error(ifr_handle h);
  * item chunks per user tile and picks the cheapest by its cost model (rounds x (tiles per chunk + a fixed cost)); "catalogue_items":
  * see ifr_pad_scores_min; "share_bounds": 0 switches the per-user bound words between item chunks off;
  * "tail_split": 0 = one grid region; "pair_topk": 0 = 16 < K <= 100 takes the candidate-buffer path like K > 100
- * ("pair_max": largest K of the pair path, default 100, at most 128);
+ * ("pair_max": largest K of the pair path, default 100, at most 128; "pair_div": that path takes one item chunk per
+ * pair_div wanted items, default 12, at most 8 chunks);
  * "wide_chunk_cap", "wide_stats": tuning / statistics of that path; "item_f64": see ifr_fit_ease (none of these
  * changes a result);
  * "csr_wave": CSR top-K kernel choice -- 0 = the workgroup-per-user kernel only; 1 (default) = one wave per user where

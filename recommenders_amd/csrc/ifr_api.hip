@@ -119,6 +119,7 @@ struct ifr_handle_s {
     int opt_wide_stats = 0;      // count the candidates of the 16 < K <= 128 path (two contended atomics per user: measurement runs only)
     int opt_wide_chunk_cap = 2;  // item chunks of that path beyond the ceil(K / 24) its bound needs (more lists loosen the bound)
     int opt_tail_split = 1;      // two-region grid: the last, partial round of workgroups runs shorter item chunks
+    int opt_pair_div = 12;       // list path (16 < K): one item chunk (two 16-entry lists per user) per pair_div wanted items
     int opt_pair_max = 100;      // largest K of that path (at most 128).  Measured against the candidate buffers: K = 50 -3 % (C2) / -10 %
                                  // (C3 shape) per pass, K = 100 -11.5 % / -5.6 % (0.7 % of the users are redone, at C3 shape from 4 MB
                                  // rows); K = 128 fills half of the 256 list slots and is redone for 9 % of the users.  With contiguous
@@ -414,6 +415,7 @@ int ifr_set_option(ifr_handle h, const char *name, int64_t value)
     else if (!strcmp(name, "share_bounds")) h->opt_share_bounds = (int)value;
     else if (!strcmp(name, "tail_split")) h->opt_tail_split = (int)value;
     else if (!strcmp(name, "pair_topk")) h->opt_pair_topk = value != 0;
+    else if (!strcmp(name, "pair_div")) h->opt_pair_div = (int)std::max<int64_t>(4, std::min<int64_t>(value, 64));
     else if (!strcmp(name, "pair_max")) h->opt_pair_max = (int)std::max<int64_t>(16, std::min<int64_t>(value, IFR_MAX_TOPK));
     else if (!strcmp(name, "item_f64")) h->opt_item_f64 = value != 0;
     else if (!strcmp(name, "wide_stats")) h->opt_wide_stats = (int)value;
@@ -1105,7 +1107,7 @@ static int rank_topk_factor(ifr_handle h, const int32_t *user_ids, int64_t n, in
     const bool pair = K > KL;
     if (pair && (K > IFR_MAX_TOPK || fixed_ws)) return fail(h, IFR_ERR_ARG, "ifr_rank_topk: internal: list path needs K <= 128 and its own workspace");
     if (pair) cap_chunks = 8;
-    const int min_chunks = pair ? std::min(8, std::max(2, (K + 11) / 12)) : 1;
+    const int min_chunks = pair ? std::min(8, std::max(2, (K + h->opt_pair_div - 1) / h->opt_pair_div)) : 1;
     const bool store = dense != nullptr;
     const size_t dyn_lds = (h->opt_debug & 64) ? 30000 : 0;     // dev ablation: extra LDS -> one workgroup per CU
     const topk_fn fn = topk_kernel_kd(h->KD, h->has_base, store, false);
