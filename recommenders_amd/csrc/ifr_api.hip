@@ -941,7 +941,7 @@ static int item_item_params(ifr_handle h, const int32_t *user_ids, int64_t n, if
     p->cptr = h->ii_cptr; p->m_idx = h->ii_idx; p->m_val = h->ii_val; p->m_pair = h->ii_pair; p->m_nnz = h->ii_nnz;
     p->fx_shift = h->mode == MODE_ITEM_CSR ? fixed_point_shift(h) : 0;
     p->dbg = h->opt_debug;
-    p->sp_cap = h->opt_csr_pass > 0 ? h->opt_csr_pass : ifr::item_sparse_pass_capacity();
+    p->sp_cap = h->opt_csr_pass > 0 ? h->opt_csr_pass : 0;          // 0: the whole buffer of the kernel that serves K
     p->pen = h->ii_pen;
     p->h_ptr = h->hs_ptr; p->h_idx = h->hs_idx; p->h_val = h->hs_val; p->h_rows = h->hs_rows;
     p->user_ids = user_ids; p->n = n; p->n_items = (int)h->n_items; p->n_chunks = h->ii_chunks;
@@ -1041,7 +1041,9 @@ int ifr_rank_topk(ifr_handle h, const int32_t *user_ids, int64_t n, int K, int32
     IFR_HIP(h, hipSetDevice(h->device));
     hipStream_t s = (hipStream_t)stream;
     if (h->mode != MODE_FACTOR) {
-        if (K > IFR_MAX_TOPK_ITEM) return fail(h, IFR_ERR_ARG, "ifr_rank_topk: item-item models: K must be in [1, 32] (larger cut-offs: ifr_score_dense + ifr_select_topk)");
+        if (h->mode == MODE_ITEM_CSR ? K > IFR_MAX_TOPK_ITEM_CSR : K > IFR_MAX_TOPK_ITEM)
+            return fail(h, IFR_ERR_ARG, h->mode == MODE_ITEM_CSR ? "ifr_rank_topk: CSR item matrix: K must be in [1, 128] (larger cut-offs: ifr_score_dense + ifr_select_topk)"
+                                                                 : "ifr_rank_topk: dense item matrix: K must be in [1, 32] (larger cut-offs: ifr_rank_topk_dense / ifr_score_dense + ifr_select_topk)");
         return rank_topk_item_item(h, user_ids, n, K, K <= 16 ? 16 : 32, out_ids, out_scores, s);
     }
     if (K > std::min(h->opt_pair_max, h->pair_limit) || (K > 16 && !h->opt_pair_topk)) return rank_topk_wide(h, user_ids, n, K, out_ids, out_scores, nullptr, 0, s);

@@ -53,6 +53,7 @@ int launch_count_long_segments(const uint32_t *cw, int64_t n_rows, int n_win, un
 int launch_build_win_ptr(const int64_t *cptr, int n_chunks, const int32_t *idx, int64_t n_rows, int n_win, uint32_t *cw, hipStream_t s);
 int item_sparse_pass_capacity();
 int item_sparse_min_capacity();
+int item_sparse_max_topk();
 int item_sparse_read_phases(unsigned long long *out16);   // dev build only (make ABLATE=1), else -1
 int item_sparse_max_chunks();
 int item_csr_pad();             // entries the CSR index / value arrays must be allocated past nnz

@@ -447,8 +447,10 @@ constexpr int SD_SPT = SP_CHUNK / SD_BLOCK;             // 16 accumulators per t
 constexpr int SD_HIST = 256;                            // history rows staged per round
 constexpr int SD_PRE = 3;                               // entries per lane prefetched one window ahead
 constexpr int SD_EXCAP = 256;                           // exclusion row entries kept in LDS
-constexpr int SD_CAND = 256;                            // candidate buffer: the list + new candidates of a window
-constexpr int SD_MAXK = 32;
+constexpr int SD_CAND = 256;                            // candidate buffer: the list + new candidates of a window (K <= 32)
+constexpr int SD_MAXK = 32;                             // ... the instantiation every K <= 32 runs on: four workgroups per CU
+constexpr int SD_MAXK_WIDE = 128;                       // 32 < K <= 128: a second instantiation, list of 128 + buffer of 512 (three per CU)
+constexpr int SD_CAND_WIDE = 512;
 constexpr int SD_FLOOR_BITS = 18;                       // bits of the short-list bound (sign + exponent + 6 of the mantissa)
 constexpr int SD_LAZY = 16;                             // (+ K) pending candidates trigger a merge
 constexpr double SD_MAGIC = 6755399441055744.0;         // 1.5 * 2^52: x + MAGIC - MAGIC = x rounded to the nearest-even integer, |x| < 2^51
@@ -486,17 +488,18 @@ __device__ unsigned long long sd_stamps[16];
 #define SD_STAMP(k) do {} while (0)
 #endif
 
-template <bool IDX32, bool LIST>
-__global__ __launch_bounds__(SD_BLOCK, 4) void item_sparse_topk_kernel(ItemItemParams p, int32_t *out_ids, float *out_scores)
+template <bool IDX32, bool LIST, int MAXK = SD_MAXK>
+__global__ __launch_bounds__(SD_BLOCK, MAXK == SD_MAXK ? 4 : 3) void item_sparse_topk_kernel(ItemItemParams p, int32_t *out_ids, float *out_scores)
 {
+    constexpr int CAND = MAXK == SD_MAXK ? SD_CAND : SD_CAND_WIDE;
     __shared__ __attribute__((aligned(16))) double tab[SP_CHUNK + 64];        // + a dummy slot per lane
     __shared__ double xs[SD_HIST];                       // history weight * 2^shift
     __shared__ int hj[SD_HIST];
     __shared__ int exl[SD_EXCAP];
-    __shared__ double cand_v[SD_CAND];
-    __shared__ int cand_c[SD_CAND];
-    __shared__ double top_v[SD_MAXK];
-    __shared__ int top_c[SD_MAXK];
+    __shared__ double cand_v[CAND];
+    __shared__ int cand_c[CAND];
+    __shared__ double top_v[MAXK];
+    __shared__ int top_c[MAXK];
     __shared__ double wred_v[SD_BLOCK / 64];
     __shared__ int wred_c[SD_BLOCK / 64];
     __shared__ uint32_t wred_n[SD_BLOCK / 64];
@@ -514,7 +517,12 @@ __global__ __launch_bounds__(SD_BLOCK, 4) void item_sparse_topk_kernel(ItemItemP
     const int u = p.user_ids[i];
     const int K = p.K;
     const int nc1 = p.n_chunks + 1;
-    const int cap = p.sp_cap;                             // candidate buffer entries in use (<= SD_CAND; tests shrink it)
+    const int cap = p.sp_cap;                             // candidate buffer entries in use (<= CAND; tests shrink it)
+    // K > 64: a wave (64 lanes) cannot count K lanes above a trial bound.  Every wave then bounds its own quarter --
+    // at least ceil(K / 4) of its lanes at or above -- and the workgroup takes the SMALLEST of the four: 4 ceil(K / 4) >= K
+    // distinct columns reach it.  (K <= 64: every wave's K-th best is a bound by itself, the largest is taken.)
+    const bool split = K > 64;
+    const int Kw = split ? (K + SD_BLOCK / 64 - 1) / (SD_BLOCK / 64) : K;
 
     int64_t hb = 0, he = 0, eb = 0, ee = 0;
     if (u >= 0 && u < p.h_rows) { hb = p.h_ptr[u]; he = p.h_ptr[u + 1]; }
@@ -675,7 +683,7 @@ __global__ __launch_bounds__(SD_BLOCK, 4) void item_sparse_topk_kernel(ItemItemP
             double lm = -INFINITY;
             for (int k = 0; k < SD_SPT; ++k) { const double vk = tab[k * SD_BLOCK + tid]; lm = (vk != 0.0 && vk > SD_LIVE) ? fmax(lm, vk) : lm; }
             double vk = -INFINITY;
-            for (int r = 0; r < K; ++r) {
+            for (int r = 0; r < Kw; ++r) {
                 vk = sd_wave_max(lm);
                 if (vk == -INFINITY) break;
                 const unsigned long long b = __ballot(lm == vk);
@@ -685,7 +693,7 @@ __global__ __launch_bounds__(SD_BLOCK, 4) void item_sparse_topk_kernel(ItemItemP
             sd_barrier();
             floor_v = wred_v[0];
 #pragma unroll
-            for (int w = 1; w < SD_BLOCK / 64; ++w) floor_v = fmax(floor_v, wred_v[w]);
+            for (int w = 1; w < SD_BLOCK / 64; ++w) floor_v = split ? fmin(floor_v, wred_v[w]) : fmax(floor_v, wred_v[w]);
             floor_v = fmax(floor_v, SD_LIVE);
             strict = false;
         }
@@ -833,13 +841,13 @@ __global__ __launch_bounds__(SD_BLOCK, 4) void item_sparse_topk_kernel(ItemItemP
 #pragma unroll
                 for (int b = 31; b > 31 - SD_FLOOR_BITS; --b) {
                     const uint32_t trial = fl | (1u << b);
-                    if (__popcll(__ballot(kmax >= trial)) >= K) fl = trial;
+                    if (__popcll(__ballot(kmax >= trial)) >= Kw) fl = trial;
                 }
                 if (lane == 0) wred_n[wave] = fl;
                 sd_barrier();
                 uint32_t floor_k = wred_n[0];
 #pragma unroll
-                for (int w = 1; w < SD_BLOCK / 64; ++w) floor_k = max(floor_k, wred_n[w]);
+                for (int w = 1; w < SD_BLOCK / 64; ++w) floor_k = split ? min(floor_k, wred_n[w]) : max(floor_k, wred_n[w]);
                 floor_k = max(floor_k, 1u);
 #pragma unroll
                 for (int t = 0; t < SD_PRE; ++t)
@@ -935,7 +943,7 @@ __global__ __launch_bounds__(SD_BLOCK, 4) void item_sparse_topk_kernel(ItemItemP
             for (int k = 0; k < SD_SPT && before < K; ++k)
                 if (okbits & (1u << k)) {
                     const int pos = atomicAdd(&s_nq, 1);
-                    cand_v[pos] = 0.0; cand_c[pos] = colA + SD_SPT * tid + k;     // cnt + (K - found) <= 2 K <= SD_CAND
+                    cand_v[pos] = 0.0; cand_c[pos] = colA + SD_SPT * tid + k;     // cnt + (K - found) <= 2 K <= cap
                     ++before;
                 }
             found += all;
@@ -1259,29 +1267,46 @@ int item_sparse_read_phases(unsigned long long *out16)
 
 int launch_item_sparse_topk(const ItemItemParams &p, int32_t *out_ids, float *out_scores, hipStream_t stream)
 {
-    if (p.n <= 0 || p.n > (int64_t)0xffffffffu / SD_BLOCK || p.K < 1 || p.K > SD_MAXK) return -1;
-    if (p.n_chunks < 1 || p.sp_cap < 2 * SD_MAXK || p.sp_cap > SD_CAND) return -1;
+    if (p.n <= 0 || p.n > (int64_t)0xffffffffu / SD_BLOCK || p.K < 1 || p.K > SD_MAXK_WIDE) return -1;
+    if (p.n_chunks < 1 || p.sp_cap < 0) return -1;
+    const bool wide = p.K > SD_MAXK;
+    // candidate buffer entries in use: all of them unless a test shrank it (never below twice the longest list)
+    const int cap_max = wide ? SD_CAND_WIDE : SD_CAND, cap_min = 2 * (wide ? SD_MAXK_WIDE : SD_MAXK);
+    const int cap = p.sp_cap == 0 ? cap_max : (p.sp_cap < cap_min ? cap_min : (p.sp_cap > cap_max ? cap_max : p.sp_cap));
     // fewer than 2^30 entries (+ the over-read pad): 32-bit entry indices from the array bases (fewer address instructions)
     const bool idx32 = p.m_nnz + II_CSR_PAD < ((int64_t)1 << 30);
+    if (wide) {                                              // 32 < K <= 128: the workgroup kernel with the long list
+        ItemItemParams q = p;
+        q.long_list = nullptr; q.long_cnt = nullptr; q.sp_cap = cap;
+        if (idx32)
+            hipLaunchKernelGGL((item_sparse_topk_kernel<true, false, SD_MAXK_WIDE>), dim3((unsigned)p.n), dim3(SD_BLOCK), 0, stream, q, out_ids, out_scores);
+        else
+            hipLaunchKernelGGL((item_sparse_topk_kernel<false, false, SD_MAXK_WIDE>), dim3((unsigned)p.n), dim3(SD_BLOCK), 0, stream, q, out_ids, out_scores);
+        return hipGetLastError() == hipSuccess ? 0 : -3;
+    }
     if (p.cptr_w != nullptr && p.long_list != nullptr && idx32) {
         // one wave per user; what that kernel hands over (long histories, lists that zero-sum columns may enter, mass
         // ties) is ranked by the workgroup kernel in list mode -- a fixed-size grid that reads the count on the device
         if (hipMemsetAsync(p.long_cnt, 0, sizeof(int), stream) != hipSuccess) return -3;
-        hipLaunchKernelGGL(item_sparse_wave_kernel, dim3((unsigned)((p.n + SW_WAVES - 1) / SW_WAVES)), dim3(64 * SW_WAVES), 0, stream, p, out_ids, out_scores);
+        ItemItemParams w = p;
+        w.sp_cap = cap;
+        hipLaunchKernelGGL(item_sparse_wave_kernel, dim3((unsigned)((p.n + SW_WAVES - 1) / SW_WAVES)), dim3(64 * SW_WAVES), 0, stream, w, out_ids, out_scores);
         const unsigned grid = (unsigned)(p.n < 2048 ? p.n : 2048);
-        hipLaunchKernelGGL((item_sparse_topk_kernel<true, true>), dim3(grid), dim3(SD_BLOCK), 0, stream, p, out_ids, out_scores);
+        hipLaunchKernelGGL((item_sparse_topk_kernel<true, true>), dim3(grid), dim3(SD_BLOCK), 0, stream, w, out_ids, out_scores);
         return hipGetLastError() == hipSuccess ? 0 : -3;
     }
     ItemItemParams q = p;
     q.long_list = nullptr; q.long_cnt = nullptr;             // direct mode: workgroup b ranks user b
+    q.sp_cap = cap;
     if (idx32)
         hipLaunchKernelGGL((item_sparse_topk_kernel<true, false>), dim3((unsigned)p.n), dim3(SD_BLOCK), 0, stream, q, out_ids, out_scores);
     else
         hipLaunchKernelGGL((item_sparse_topk_kernel<false, false>), dim3((unsigned)p.n), dim3(SD_BLOCK), 0, stream, q, out_ids, out_scores);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
-int item_sparse_pass_capacity() { return SD_CAND; }
+int item_sparse_pass_capacity() { return SD_CAND_WIDE; }
 int item_sparse_min_capacity() { return 2 * SD_MAXK; }
+int item_sparse_max_topk() { return SD_MAXK_WIDE; }
 int item_sparse_max_chunks() { return 1 << 20; }
 
 // fp64 option: one wave per user ranks the n_lists * KL partial entries by counting (score descending on the DOUBLES,

@@ -13,7 +13,8 @@ from . import _lib
 METRICS_PER_K = 6      # ndcg, recall, precision, hit ratio, f1, ncrr (include/ifr.h IFR_METRICS_PER_K)
 METRIC_COLUMNS = ("ndcg", "recall", "precision", "hit", "f1", "ncrr")
 MAX_FUSED_TOPK = 128   # ifr_rank_topk, dot-product models (include/ifr.h IFR_MAX_TOPK)
-MAX_FUSED_TOPK_ITEM = 32   # ifr_rank_topk, item-item models (IFR_MAX_TOPK_ITEM)
+MAX_FUSED_TOPK_ITEM = 32   # ifr_rank_topk, dense item matrix (IFR_MAX_TOPK_ITEM)
+MAX_FUSED_TOPK_ITEM_CSR = 128   # ... CSR item matrix (IFR_MAX_TOPK_ITEM_CSR)
 MAX_TOPK_METRICS = 128 # ifr_eval_topk_metrics
 MAX_SELECT_TOPK = 1024 # ifr_select_topk
 MAX_DENSE_METRIC_POS = 4096   # ifr_eval_dense_metrics: positives per row
@@ -339,7 +340,7 @@ class HipScorer:
     # ------------------------------------------------------------------ compute
     def rank_topk(self, user_ids, K, out_ids=None, out_scores=None, dense_batch_pairs=1 << 28):
         """Top-K (ids int32 [n,K], scores fp32 [n,K]) for the listed users: the fused kernel up to K = 128 (item-item
-        models: 32), dense rows + partial ranking up to K = 1024 (`dense_batch_pairs` bounds users x items of one
+        models: 32 with a dense item matrix, 128 with a CSR one), dense rows + partial ranking up to K = 1024 (`dense_batch_pairs` bounds users x items of one
         dense batch)."""
         torch = _torch()
         u = self._dev_users(user_ids)
@@ -364,7 +365,9 @@ class HipScorer:
 
     def max_fused_topk(self):
         """Largest K ifr_rank_topk serves for the model that is set."""
-        return MAX_FUSED_TOPK if self.item_model is None else MAX_FUSED_TOPK_ITEM
+        if self.item_model is None:
+            return MAX_FUSED_TOPK
+        return MAX_FUSED_TOPK_ITEM_CSR if self.item_model == "csr" else MAX_FUSED_TOPK_ITEM
 
     def wide_overflows(self):
         """Users the 16 < K <= 128 path ranked from dense rows so far because their candidate buffer overflowed."""

@@ -99,7 +99,7 @@ def test_c5_shape_csr_125000_items_256_neighbours_bit_exact(torch, cand_cap, wav
     users = np.r_[np.arange(len(lengths)), [len(lengths) + 9]].astype(np.int32)
     shift = sc.item_fixed_point_shift()
     assert shift == orc.item_fixed_point_shift(m_val, h_ptr, h_val, m_idx, col_scale)
-    for K in (10, 32):
+    for K in (10, 32, 100):
         ids, scores = sc.rank_topk(users, K)
         per_user, _, _ = sc.eval_topk_metrics(users, ids, [K])
         o_ids, o_sc, o_met, _ = orc.c_ranking_eval_item(None, (m_ptr, m_idx, m_val), shift, n_items, col_scale, h_ptr, h_idx, h_val,

@@ -82,7 +82,11 @@ def test_dense_topk_bit_exact_vs_oracle(torch, n_items, K, pen):
     np.testing.assert_array_equal(scores.cpu().numpy(), o_sc)
 
 
-@pytest.mark.parametrize("n_items,row_nnz,K,pen", [(3001, 40, 10, True), (10000, 120, 20, False), (20000, 300, 10, True), (9000, 12, 32, False)])
+@pytest.mark.parametrize("n_items,row_nnz,K,pen", [(3001, 40, 10, True), (10000, 120, 20, False), (20000, 300, 10, True), (9000, 12, 32, False),
+                                                   # 32 < K <= 128: the workgroup kernel's long-list instantiation (K > 64: the short-list
+                                                   # bound is split over the four waves); 12 entries per row: lists that end short
+                                                   (10000, 120, 100, True), (3001, 40, 128, False), (20000, 300, 64, True), (9000, 12, 65, False),
+                                                   (9000, 12, 33, True)])
 def test_csr_topk_bit_exact_vs_oracle(torch, n_items, row_nnz, K, pen):
     w = _workload(50 + K, 301, n_items, 30, row_nnz=row_nnz, weights="prob", pen=pen)
     sc = _scorer(w)
@@ -112,7 +116,7 @@ def test_csr_topk_pass_shapes(torch, pass_entries, wave):
     if pass_entries:
         sc.set_option("csr_cand_cap", pass_entries)
     users = np.r_[np.arange(w["n_users"]), [w["n_users"] + 5]].astype(np.int32)
-    for K in (10, 32):
+    for K in (10, 32, 48, 100, 128):            # (K > 32: the buffer of 512 is cut to 256 by the same option)
         ids, scores = sc.rank_topk(users, K)
         o_ids, o_sc, _, _ = _oracle(w, sc, users, [K], K)
         np.testing.assert_array_equal(ids.cpu().numpy(), o_ids)
@@ -123,10 +127,11 @@ def test_csr_topk_pass_shapes(torch, pass_entries, wave):
     sc.set_option("csr_wave", wave)
     if pass_entries:
         sc.set_option("csr_cand_cap", pass_entries)
-    ids, scores = sc.rank_topk(users, 10)
-    o_ids, o_sc, _, _ = _oracle(w, sc, users, [10], 10)
-    np.testing.assert_array_equal(ids.cpu().numpy(), o_ids)
-    np.testing.assert_array_equal(scores.cpu().numpy(), o_sc)
+    for K in (10, 100):
+        ids, scores = sc.rank_topk(users, K)
+        o_ids, o_sc, _, _ = _oracle(w, sc, users, [K], K)
+        np.testing.assert_array_equal(ids.cpu().numpy(), o_ids)
+        np.testing.assert_array_equal(scores.cpu().numpy(), o_sc)
 
 
 def test_csr_equals_dense_form_within_fp32_rounding(torch):
@@ -181,6 +186,18 @@ def test_fewer_candidates_than_k_and_ties(torch):
         np.testing.assert_array_equal(ids[1], np.r_[35:40, [-1] * 5])
         np.testing.assert_array_equal(ids[2], np.arange(10))                  # all scores equal 2.0
         assert (scores[2] == 2.0).all() and np.isneginf(scores[0]).all()
+        if form == "csr":                        # a list longer than the catalogue: 40 columns, K = 70
+            ids, scores = sc.rank_topk(np.arange(5, dtype=np.int32), 70)
+            ids, scores = ids.cpu().numpy(), scores.cpu().numpy()
+            np.testing.assert_array_equal(ids[2], np.r_[0:40, [-1] * 30])
+            np.testing.assert_array_equal(ids[1], np.r_[35:40, [-1] * 65])
+            assert (ids[0] == -1).all() and (scores[2][:40] == 2.0).all() and np.isneginf(scores[2][40:]).all()
+            # the C entry point itself refuses K > 128 (the facade serves those from dense rows)
+            u1 = torch.zeros(1, dtype=torch.int32, device="cuda")
+            oi, os_ = torch.empty((1, 129), dtype=torch.int32, device="cuda"), torch.empty((1, 129), dtype=torch.float32, device="cuda")
+            assert sc._lib.ifr_rank_topk(sc._h, u1.data_ptr(), 1, 129, oi.data_ptr(), os_.data_ptr(), None) != 0
+            big, _ = sc.rank_topk(np.arange(5, dtype=np.int32), 129)
+            np.testing.assert_array_equal(big.cpu().numpy()[2], np.r_[0:40, [-1] * 89])
 
 
 def test_bad_inputs_are_rejected(torch):

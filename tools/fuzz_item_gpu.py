@@ -15,6 +15,8 @@ for case in range(cases):
     n_users = int(rng.choice([1, 33, 200, 700]))
     n_items = int(rng.choice([40, 1000, 4097, 9000, 20000])) if form == "csr" else int(rng.choice([40, 1000, 4097, 9000]))
     K = int(rng.choice([1, 5, 10, 20, 32]))
+    if form == "csr" and rng.integers(2):
+        K = int(rng.choice([33, 50, 64, 65, 100, 128]))
     mean_hist = float(rng.choice([0.5, 5, 40, 300]))
     pen = bool(rng.integers(2))
     neg = bool(rng.integers(2))
@@ -52,7 +54,7 @@ for case in range(cases):
     sc.set_exclusion_csr(e_ptr, e_idx)
     sc.set_truth_csr(np.zeros(n_users + 1, np.int64), np.zeros(0, np.int32))
     if form == "csr" and rng.integers(2):
-        sc.set_option("csr_cand_cap", int(rng.choice([64, 100, 256])))
+        sc.set_option("csr_cand_cap", int(rng.choice([64, 100, 256, 300])))
     if form == "csr":
         sc.set_option("csr_wave", int(rng.choice([0, 2])))              # the wave-per-user kernel forced (+ hand-over), or the workgroup kernel alone
     t = time.perf_counter()
