@@ -63,8 +63,8 @@ const char *ifr_last_error(ifr_handle h);
  * 1024-column window) segments hold more than the three entries that kernel prefetches (measured when the matrix is
  * set: evenly spread rows; on matrices with uniformly drawn columns the workgroup kernel is the faster one); 2 = force
  * the wave kernel (tests).  Same results either way;
- * "csr_cand_cap": candidate buffer entries of the CSR top-K kernel (K <= 32: 64 ... 256, 0 = default 256; K > 32:
- * 256 ... 512, default 512; a value outside is clamped; tests shrink it to force the overflow path; no result changes);
+ * "csr_cand_cap": entries of the CSR top-K kernel's buffer of candidates that wait to be merged into a user's list
+ * (K ... 256, 0 = default 256; a value outside is clamped; tests shrink it to force the overflow path; no result changes);
  * "debug_mode": development ablations (results may change; the fused kernel's modes, bits 0-2
  * and 7 of "debug_mode", exist only in a library built with `make ABLATE=1` / `STAMPS=1` and are refused with
  * IFR_ERR_ARG otherwise; bit 6 = one workgroup per CU works everywhere).  Options are per handle and
@@ -201,8 +201,8 @@ int ifr_read_eval_csr(ifr_handle h, int which, int64_t *indptr, int32_t *indices
  * ascending on ties.  out_ids/out_scores: dev [n][K]; unfilled slots (fewer than K
  * candidates) hold id -1 / score -inf.  user_ids: dev [n].
  * 1 <= K <= IFR_MAX_TOPK for dot-product models, IFR_MAX_TOPK_ITEM for dense item matrices, IFR_MAX_TOPK_ITEM_CSR for
- * CSR item matrices (K <= 32: list of 32 in LDS, four workgroups per CU, histories <= 64 rows by the wave-per-user
- * kernel; 32 < K <= 128: the workgroup kernel with a list of 128 and a buffer of 512).  Dot-product models, K <= 16: lane-private
+ * CSR item matrices (K <= 32: histories of at most 64 rows by the wave-per-user kernel where the matrix suits it, see
+ * "csr_wave"; everything else by the workgroup-per-user kernel).  Dot-product models, K <= 16: lane-private
  * sorted lists, merged per user; the call is asynchronous on `stream`.  16 < K <= 100 (dot-product models): the same
  * kernel; a user's two 16-entry lists per item chunk (2 ... 8 chunks, about K / 12) hold the top K unless more than
  * 16 of them fall into one list -- the merge sees that (a full list whose last entry ranks before the user's K-th)

@@ -446,13 +446,12 @@ constexpr int SD_BLOCK = 256;                           // threads per user
 constexpr int SD_SPT = SP_CHUNK / SD_BLOCK;             // 16 accumulators per thread
 constexpr int SD_HIST = 256;                            // history rows staged per round
 constexpr int SD_PRE = 3;                               // entries per lane prefetched one window ahead
-constexpr int SD_EXCAP = 256;                           // exclusion row entries kept in LDS
-constexpr int SD_CAND = 256;                            // candidate buffer: the list + new candidates of a window (K <= 32)
-constexpr int SD_MAXK = 32;                             // ... the instantiation every K <= 32 runs on: four workgroups per CU
-constexpr int SD_MAXK_WIDE = 128;                       // 32 < K <= 128: a second instantiation, list of 128 + buffer of 512 (three per CU)
-constexpr int SD_CAND_WIDE = 512;
+constexpr int SD_EXCAP = 224;                           // exclusion row entries kept in LDS
+constexpr int SD_CAND = 256;                            // candidate buffer: the new candidates that wait to be merged into the list
+constexpr int SD_MAXK = 128;                            // longest list (LDS of a workgroup: 40 912 B, four workgroups per CU for every K)
 constexpr int SD_FLOOR_BITS = 18;                       // bits of the short-list bound (sign + exponent + 6 of the mantissa)
-constexpr int SD_LAZY = 16;                             // (+ K) pending candidates trigger a merge
+constexpr int SD_LAZY = 16;                             // (+ K) pending candidates trigger a merge ...
+constexpr int SD_LAZY_MAX = 48;                         // ... at most this many (measured at K = 50 ... 128: 16, 32, 48, 56, 16 + K)
 constexpr double SD_MAGIC = 6755399441055744.0;         // 1.5 * 2^52: x + MAGIC - MAGIC = x rounded to the nearest-even integer, |x| < 2^51
 constexpr double SD_POISON = -1152921504606846976.0;    // -2^60: an excluded column
 constexpr double SD_LIVE = -288230376151711744.0;       // -2^58: sums above are real (|sum| < 2^52)
@@ -488,18 +487,17 @@ __device__ unsigned long long sd_stamps[16];
 #define SD_STAMP(k) do {} while (0)
 #endif
 
-template <bool IDX32, bool LIST, int MAXK = SD_MAXK>
-__global__ __launch_bounds__(SD_BLOCK, MAXK == SD_MAXK ? 4 : 3) void item_sparse_topk_kernel(ItemItemParams p, int32_t *out_ids, float *out_scores)
+template <bool IDX32, bool LIST>
+__global__ __launch_bounds__(SD_BLOCK, 4) void item_sparse_topk_kernel(ItemItemParams p, int32_t *out_ids, float *out_scores)
 {
-    constexpr int CAND = MAXK == SD_MAXK ? SD_CAND : SD_CAND_WIDE;
     __shared__ __attribute__((aligned(16))) double tab[SP_CHUNK + 64];        // + a dummy slot per lane
-    __shared__ double xs[SD_HIST];                       // history weight * 2^shift
+    __shared__ float xf[SD_HIST];                        // history weights
     __shared__ int hj[SD_HIST];
     __shared__ int exl[SD_EXCAP];
-    __shared__ double cand_v[CAND];
-    __shared__ int cand_c[CAND];
-    __shared__ double top_v[MAXK];
-    __shared__ int top_c[MAXK];
+    __shared__ double cand_v[SD_CAND];
+    __shared__ int cand_c[SD_CAND];
+    __shared__ double top_v[SD_MAXK];
+    __shared__ int top_c[SD_MAXK];
     __shared__ double wred_v[SD_BLOCK / 64];
     __shared__ int wred_c[SD_BLOCK / 64];
     __shared__ uint32_t wred_n[SD_BLOCK / 64];
@@ -517,10 +515,11 @@ __global__ __launch_bounds__(SD_BLOCK, MAXK == SD_MAXK ? 4 : 3) void item_sparse
     const int u = p.user_ids[i];
     const int K = p.K;
     const int nc1 = p.n_chunks + 1;
-    const int cap = p.sp_cap;                             // candidate buffer entries in use (<= CAND; tests shrink it)
+    const int cap = p.sp_cap;                             // candidate buffer entries in use (K ... SD_CAND; tests shrink it)
     // K > 64: a wave (64 lanes) cannot count K lanes above a trial bound.  Every wave then bounds its own quarter --
     // at least ceil(K / 4) of its lanes at or above -- and the workgroup takes the SMALLEST of the four: 4 ceil(K / 4) >= K
     // distinct columns reach it.  (K <= 64: every wave's K-th best is a bound by itself, the largest is taken.)
+    const int lazy = min(SD_LAZY + K, SD_LAZY_MAX);     // pending candidates that trigger a merge while the list is full
     const bool split = K > 64;
     const int Kw = split ? (K + SD_BLOCK / 64 - 1) / (SD_BLOCK / 64) : K;
 
@@ -536,7 +535,7 @@ __global__ __launch_bounds__(SD_BLOCK, MAXK == SD_MAXK ? 4 : 3) void item_sparse
     if (ex_lds) for (int w = tid; w < (int)n_ex; w += SD_BLOCK) exl[w] = p.ex_idx[eb + w];
     if (tid == 0) { s_nq = 0; s_cnt = 0; s_dead = 0; }
     auto stage = [&](int64_t base, int m) {
-        for (int e = tid; e < m; e += SD_BLOCK) { hj[e] = p.h_idx[base + e]; xs[e] = ldexp((double)p.h_val[base + e], p.fx_shift); }
+        for (int e = tid; e < m; e += SD_BLOCK) { hj[e] = p.h_idx[base + e]; xf[e] = p.h_val[base + e]; }
     };
     if (single) stage(hb, m1);
     sd_barrier();
@@ -571,7 +570,7 @@ __global__ __launch_bounds__(SD_BLOCK, MAXK == SD_MAXK ? 4 : 3) void item_sparse
         for (int e = tid / L; e < m; e += rows_at_once) {
             const int64_t *cp = p.cptr + (int64_t)hj[e] * nc1 + c;
             const int64_t q0 = cp[0], q1 = cp[1];
-            const double x = xs[e];
+            const double x = ldexp((double)xf[e], p.fx_shift);      // history weight * 2^shift
             for (int64_t q = q0 + l; q < q1; q += L) {
                 const uint2 e2 = p.m_pair[q];
                 const double r = fma(x, (double)__uint_as_float(e2.y), SD_MAGIC) - SD_MAGIC;     // exact product, nearest-even integer
@@ -591,28 +590,50 @@ __global__ __launch_bounds__(SD_BLOCK, MAXK == SD_MAXK ? 4 : 3) void item_sparse
             }
         }
     };
-    // cand[0, cnt) <- the list; cand[cnt, s_nq) = new candidates  ->  the new list.  Call after a barrier.
+    // the list (top_*[0, cnt), sorted) + the new candidates cand[0, s_nq)  ->  the new list.  Call after a barrier.
+    // Ranks by counting, but only against what is NOT sorted yet: a list entry keeps its position plus the number of
+    // candidates that beat it; a candidate's rank is its position in the list (binary search) plus the number of
+    // candidates that beat it.  (Counting every entry against every entry cost (K + P)^2 compares for P candidates:
+    // at K = 100 the merges were 3/4 of the kernel's instructions.)  List entries sit on the low threads, candidates
+    // on the high ones, so that the waves share the work.
     // (check_ex: the new candidates have not been looked up in the user's exclusion row yet -- the entry-driven path
     // defers that to here, where one lookup per candidate runs for all of them at once)
     auto rank_merge = [&](bool check_ex) __attribute__((always_inline)) {
         const int total = s_nq, cnt = s_cnt;
-        if (tid < cnt) { cand_v[tid] = top_v[tid]; cand_c[tid] = top_c[tid]; }
-        if (check_ex && n_ex != 0)
-            for (int e = cnt + tid; e < total; e += SD_BLOCK) {
-                const int col = cand_c[e];
+        if (check_ex && n_ex != 0) {
+            if (tid < total) {
+                const int col = cand_c[tid];
                 const int64_t w = ex_lower_bound(col);
-                if (w < n_ex && (ex_lds ? exl[w] : p.ex_idx[eb + w]) == col) { cand_v[e] = -INFINITY; atomicAdd(&s_dead, 1); }
+                if (w < n_ex && (ex_lds ? exl[w] : p.ex_idx[eb + w]) == col) { cand_v[tid] = -INFINITY; atomicAdd(&s_dead, 1); }
             }
-        sd_barrier();
-        for (int e = tid; e < total; e += SD_BLOCK) {
-            const double v = cand_v[e];
-            const int c = cand_c[e];
-            int r = 0;
-            for (int x = 0; x < total; ++x) r += sd_beats(cand_v[x], cand_c[x], v, c) ? 1 : 0;
-            if (r < K && v != -INFINITY) { top_v[r] = v; top_c[r] = c; }
+            sd_barrier();
         }
+        int r_list = K;
+        double lv = 0.0;
+        int lc = 0;
+        if (tid < cnt) {
+            lv = top_v[tid]; lc = top_c[tid];
+            int b = 0;
+            for (int x = 0; x < total; ++x) b += sd_beats(cand_v[x], cand_c[x], lv, lc) ? 1 : 0;
+            r_list = tid + b;
+        }
+        int r_new = K;
+        double nv = 0.0;
+        int ncol = 0;
+        const int e = SD_BLOCK - 1 - tid;                 // (SD_CAND == SD_BLOCK: at most one candidate per thread)
+        if (e < total) {
+            nv = cand_v[e]; ncol = cand_c[e];
+            int lo = 0, hi = cnt;                         // list entries that beat it: the list is sorted
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (sd_beats(top_v[mid], top_c[mid], nv, ncol)) lo = mid + 1; else hi = mid; }
+            int b = lo;
+            for (int x = 0; x < total; ++x) b += sd_beats(cand_v[x], cand_c[x], nv, ncol) ? 1 : 0;
+            if (nv != -INFINITY) r_new = b;
+        }
+        sd_barrier();                                     // every read of the old list is done
+        if (r_list < K) { top_v[r_list] = lv; top_c[r_list] = lc; }
+        if (r_new < K) { top_v[r_new] = nv; top_c[r_new] = ncol; }
         sd_barrier();
-        if (tid == 0) { const int n = min(K, total - s_dead); s_cnt = n; s_nq = n; s_dead = 0; }
+        if (tid == 0) { s_cnt = min(K, cnt + total - s_dead); s_nq = 0; s_dead = 0; }
         sd_barrier();
     };
     // exact fallback: the K best of (list U the window's candidates) by K rounds of a block-wide argmax over the sums that
@@ -661,7 +682,7 @@ __global__ __launch_bounds__(SD_BLOCK, MAXK == SD_MAXK ? 4 : 3) void item_sparse
         }
         for (int k = 0; k < SD_SPT; ++k) tab[k * SD_BLOCK + tid] = 0.0;
         sd_barrier();
-        if (tid == 0) { s_cnt = filled; s_nq = filled; }
+        if (tid == 0) { s_cnt = filled; s_nq = 0; }
         sd_barrier();
     };
 
@@ -721,7 +742,7 @@ __global__ __launch_bounds__(SD_BLOCK, MAXK == SD_MAXK ? 4 : 3) void item_sparse
         sd_barrier();                                  // appends done; every slot without a candidate is clean
         const int total = s_nq;
         if (total > cap) argmax_rounds(colA, floor_v, strict);      // more candidates than the buffer holds (mass ties): exact rounds
-        else if (total > cnt) {
+        else if (total > 0) {
             for (int k = 0; k < SD_SPT; ++k) if (mine & (1u << k)) tab[k * SD_BLOCK + tid] = 0.0;
             rank_merge(false);
         }
@@ -737,7 +758,7 @@ __global__ __launch_bounds__(SD_BLOCK, MAXK == SD_MAXK ? 4 : 3) void item_sparse
         const int e = tid / L, l = tid - e * L;
         const bool has_row = e < m1;
         const int64_t *cpb = p.cptr + (int64_t)(has_row ? hj[e] : 0) * nc1;
-        const double x = has_row ? xs[e] : 0.0;
+        const double x = has_row ? ldexp((double)xf[e], p.fx_shift) : 0.0;      // history weight * 2^shift
         // entry positions as 32-bit offsets from the row's first entry (a row has fewer than 2^31 entries); IDX32: the whole
         // matrix has fewer than 2^30 entries, so a 32-bit index addresses any of them from the (uniform) array base
         const int64_t row0q = has_row ? cpb[0] : 0;
@@ -786,7 +807,7 @@ __global__ __launch_bounds__(SD_BLOCK, MAXK == SD_MAXK ? 4 : 3) void item_sparse
         // read once, cleared, and owned by exactly one lane -- no scan of the 4096 slots, no poison for the exclusions (a
         // candidate is looked up in the user's exclusion row instead: after the first windows candidates are rare).
         // Lanes without an entry swap a private dummy slot behind the table.
-        int cnt_r = 0, nq_prev = 0;                       // register copies of s_cnt / s_nq at the window's start / the list's K-th sum
+        int cnt_r = 0, nq_prev = 0;                       // register copies of s_cnt / s_nq (candidates pending) at the window's start; the list's K-th sum
         double tau = 0.0;
         auto excluded = [&](int col) __attribute__((always_inline)) -> bool {
             if (n_ex == 0) return false;
@@ -864,15 +885,15 @@ __global__ __launch_bounds__(SD_BLOCK, MAXK == SD_MAXK ? 4 : 3) void item_sparse
                 sd_barrier();                             // (everybody has read s_nq)
                 if (tid == 0) s_nq = nq_prev;
                 sd_barrier();
-                if (nq_prev > cnt_r) rank_merge(true);
+                if (nq_prev > 0) rank_merge(true);
                 accumulate_rows(m1, c, colA);
                 scan_and_select(colA);
-                cnt_r = s_cnt; tau = top_v[K - 1]; nq_prev = cnt_r;
-            } else if (total > cnt_r && (!full || total - cnt_r >= SD_LAZY + K || total + SD_LAZY + K > cap)) {
+                cnt_r = s_cnt; tau = top_v[K - 1]; nq_prev = 0;
+            } else if (total > 0 && (!full || total >= lazy || total + lazy > cap)) {
                 // LAZY merge: while the list is full, new candidates wait behind it (the stale K-th sum only admits a few
                 // more) until SD_LAZY + K of them are pending: ~4 merges per user instead of one in every second window
                 rank_merge(true);
-                cnt_r = s_cnt; tau = top_v[K - 1]; nq_prev = cnt_r;
+                cnt_r = s_cnt; tau = top_v[K - 1]; nq_prev = 0;
             } else nq_prev = total;
         };
         auto window = [&](int c, const Pre &cur, Pre &nxt) __attribute__((always_inline)) {
@@ -895,7 +916,7 @@ __global__ __launch_bounds__(SD_BLOCK, MAXK == SD_MAXK ? 4 : 3) void item_sparse
             window(c, A, B);
             if (c + 1 < p.n_chunks) window(c + 1, B, A);
         }
-        if (nq_prev > cnt_r) rank_merge(true);                      // the candidates still pending
+        if (nq_prev > 0) rank_merge(true);                          // the candidates still pending
         SD_STAMP(7);
     } else {
         for (int c = 0; c < p.n_chunks; ++c) {
@@ -943,12 +964,12 @@ __global__ __launch_bounds__(SD_BLOCK, MAXK == SD_MAXK ? 4 : 3) void item_sparse
             for (int k = 0; k < SD_SPT && before < K; ++k)
                 if (okbits & (1u << k)) {
                     const int pos = atomicAdd(&s_nq, 1);
-                    cand_v[pos] = 0.0; cand_c[pos] = colA + SD_SPT * tid + k;     // cnt + (K - found) <= 2 K <= cap
+                    cand_v[pos] = 0.0; cand_c[pos] = colA + SD_SPT * tid + k;     // K - found <= K <= cap
                     ++before;
                 }
             found += all;
             sd_barrier();
-            if (s_nq > cnt) rank_merge(false);
+            if (s_nq > 0) rank_merge(false);
         }
     }
     sd_barrier();
@@ -991,6 +1012,7 @@ __global__ __launch_bounds__(SD_BLOCK, MAXK == SD_MAXK ? 4 : 3) void item_sparse
 constexpr int SW_WIN = 1024;                            // columns per window
 constexpr int SW_PRE = 3;                               // entries per lane prefetched one window ahead
 constexpr int SW_CAND = 96;                             // the list + pending candidates
+constexpr int SW_MAXK = 32;                             // longest list of this kernel (longer ones: the workgroup kernel)
 constexpr int SW_EXL = 32;                              // exclusion row entries kept in LDS
 constexpr int SW_WAVES = 4;
 
@@ -1267,24 +1289,13 @@ int item_sparse_read_phases(unsigned long long *out16)
 
 int launch_item_sparse_topk(const ItemItemParams &p, int32_t *out_ids, float *out_scores, hipStream_t stream)
 {
-    if (p.n <= 0 || p.n > (int64_t)0xffffffffu / SD_BLOCK || p.K < 1 || p.K > SD_MAXK_WIDE) return -1;
+    if (p.n <= 0 || p.n > (int64_t)0xffffffffu / SD_BLOCK || p.K < 1 || p.K > SD_MAXK) return -1;
     if (p.n_chunks < 1 || p.sp_cap < 0) return -1;
-    const bool wide = p.K > SD_MAXK;
-    // candidate buffer entries in use: all of them unless a test shrank it (never below twice the longest list)
-    const int cap_max = wide ? SD_CAND_WIDE : SD_CAND, cap_min = 2 * (wide ? SD_MAXK_WIDE : SD_MAXK);
-    const int cap = p.sp_cap == 0 ? cap_max : (p.sp_cap < cap_min ? cap_min : (p.sp_cap > cap_max ? cap_max : p.sp_cap));
+    // candidate buffer entries in use: all of them unless a test shrank it (never below K: the zero-sum sweep parks up to K)
+    const int cap = p.sp_cap == 0 ? SD_CAND : (p.sp_cap < p.K ? p.K : (p.sp_cap > SD_CAND ? SD_CAND : p.sp_cap));
     // fewer than 2^30 entries (+ the over-read pad): 32-bit entry indices from the array bases (fewer address instructions)
     const bool idx32 = p.m_nnz + II_CSR_PAD < ((int64_t)1 << 30);
-    if (wide) {                                              // 32 < K <= 128: the workgroup kernel with the long list
-        ItemItemParams q = p;
-        q.long_list = nullptr; q.long_cnt = nullptr; q.sp_cap = cap;
-        if (idx32)
-            hipLaunchKernelGGL((item_sparse_topk_kernel<true, false, SD_MAXK_WIDE>), dim3((unsigned)p.n), dim3(SD_BLOCK), 0, stream, q, out_ids, out_scores);
-        else
-            hipLaunchKernelGGL((item_sparse_topk_kernel<false, false, SD_MAXK_WIDE>), dim3((unsigned)p.n), dim3(SD_BLOCK), 0, stream, q, out_ids, out_scores);
-        return hipGetLastError() == hipSuccess ? 0 : -3;
-    }
-    if (p.cptr_w != nullptr && p.long_list != nullptr && idx32) {
+    if (p.cptr_w != nullptr && p.long_list != nullptr && idx32 && p.K <= SW_MAXK) {
         // one wave per user; what that kernel hands over (long histories, lists that zero-sum columns may enter, mass
         // ties) is ranked by the workgroup kernel in list mode -- a fixed-size grid that reads the count on the device
         if (hipMemsetAsync(p.long_cnt, 0, sizeof(int), stream) != hipSuccess) return -3;
@@ -1304,9 +1315,9 @@ int launch_item_sparse_topk(const ItemItemParams &p, int32_t *out_ids, float *ou
         hipLaunchKernelGGL((item_sparse_topk_kernel<false, false>), dim3((unsigned)p.n), dim3(SD_BLOCK), 0, stream, q, out_ids, out_scores);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
-int item_sparse_pass_capacity() { return SD_CAND_WIDE; }
-int item_sparse_min_capacity() { return 2 * SD_MAXK; }
-int item_sparse_max_topk() { return SD_MAXK_WIDE; }
+int item_sparse_pass_capacity() { return SD_CAND; }
+int item_sparse_min_capacity() { return 1; }
+int item_sparse_max_topk() { return SD_MAXK; }
 int item_sparse_max_chunks() { return 1 << 20; }
 
 // fp64 option: one wave per user ranks the n_lists * KL partial entries by counting (score descending on the DOUBLES,

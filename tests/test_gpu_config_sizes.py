@@ -71,11 +71,11 @@ def test_c4_shape_dense_50000_items_bit_exact(torch):
     del B
 
 
-@pytest.mark.parametrize("cand_cap,wave", [(0, 1), (0, 2), (0, 0), (64, 0)])
+@pytest.mark.parametrize("cand_cap,wave", [(0, 1), (0, 2), (0, 0), (32, 0)])
 def test_c5_shape_csr_125000_items_256_neighbours_bit_exact(torch, cand_cap, wave):
     """31 windows per user; a user with 400 history rows (staging rounds, ~3 300 entries per window, an exclusion row
     beyond the LDS copy), one with 200 rows (one lane per row, segments longer than the prefetch), a single-row user, a
-    user without history and one past the last row; with the candidate buffer cut to 64 entries the first windows
+    user without history and one past the last row; with the candidate buffer cut to max(32, K) entries the first windows
     overflow it and are ranked by the exact argmax rounds."""
     from recommenders_amd import HipScorer, synth
     n_items, nnz = 125_000, 256

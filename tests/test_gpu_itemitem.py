@@ -102,9 +102,9 @@ def test_csr_topk_bit_exact_vs_oracle(torch, n_items, row_nnz, K, pen):
                                                                    w["col_scale"])
 
 
-@pytest.mark.parametrize("pass_entries,wave", [(0, 2), (0, 0), (64, 0)])
+@pytest.mark.parametrize("pass_entries,wave", [(0, 2), (0, 0), (32, 0)])
 def test_csr_topk_pass_shapes(torch, pass_entries, wave):
-    """The CSR top-K kernel over its paths: candidates ranked by counting and -- candidate buffer cut to 64 entries,
+    """The CSR top-K kernel over its paths: candidates ranked by counting and -- candidate buffer cut to max(32, K) entries,
     which the first windows of these users overflow -- by the exact block-wide argmax rounds; histories longer than a
     staging round (128 rows), exclusion rows beyond the LDS copy (256 entries), negative values (zero-sum columns
     enter the list) and users without history."""
@@ -116,7 +116,7 @@ def test_csr_topk_pass_shapes(torch, pass_entries, wave):
     if pass_entries:
         sc.set_option("csr_cand_cap", pass_entries)
     users = np.r_[np.arange(w["n_users"]), [w["n_users"] + 5]].astype(np.int32)
-    for K in (10, 32, 48, 100, 128):            # (K > 32: the buffer of 512 is cut to 256 by the same option)
+    for K in (10, 32, 48, 100, 128):
         ids, scores = sc.rank_topk(users, K)
         o_ids, o_sc, _, _ = _oracle(w, sc, users, [K], K)
         np.testing.assert_array_equal(ids.cpu().numpy(), o_ids)

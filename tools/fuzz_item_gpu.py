@@ -54,7 +54,7 @@ for case in range(cases):
     sc.set_exclusion_csr(e_ptr, e_idx)
     sc.set_truth_csr(np.zeros(n_users + 1, np.int64), np.zeros(0, np.int32))
     if form == "csr" and rng.integers(2):
-        sc.set_option("csr_cand_cap", int(rng.choice([64, 100, 256, 300])))
+        sc.set_option("csr_cand_cap", int(rng.choice([16, 40, 100, 256])))
     if form == "csr":
         sc.set_option("csr_wave", int(rng.choice([0, 2])))              # the wave-per-user kernel forced (+ hand-over), or the workgroup kernel alone
     t = time.perf_counter()
