@@ -632,8 +632,7 @@ __global__ __launch_bounds__(SD_BLOCK, 4) void item_sparse_topk_kernel(ItemItemP
         sd_barrier();                                     // every read of the old list is done
         if (r_list < K) { top_v[r_list] = lv; top_c[r_list] = lc; }
         if (r_new < K) { top_v[r_new] = nv; top_c[r_new] = ncol; }
-        sd_barrier();
-        if (tid == 0) { s_cnt = min(K, cnt + total - s_dead); s_nq = 0; s_dead = 0; }
+        if (tid == 0) { s_cnt = min(K, cnt + total - s_dead); s_nq = 0; s_dead = 0; }      // (everybody read them before the barrier above)
         sd_barrier();
     };
     // exact fallback: the K best of (list U the window's candidates) by K rounds of a block-wide argmax over the sums that
