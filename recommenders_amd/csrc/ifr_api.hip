@@ -801,7 +801,7 @@ int ifr_set_item_matrix_csr(ifr_handle h, const int64_t *indptr, const int32_t *
         }
         if (!lrc) {                              // entry offsets per 1024-column window, where the table stays modest
             const int n_win = ifr::item_sparse_wave_windows((int)n_items);
-            const size_t wbytes = sizeof(uint32_t) * (size_t)n_items * (size_t)(n_win + 1);
+            const size_t wbytes = sizeof(uint32_t) * (size_t)n_items * (size_t)ifr::item_sparse_wave_stride(n_win);
             if (wbytes <= ((size_t)1 << 30) && nnz + ifr::item_csr_pad() < ((int64_t)1 << 30) &&
                 hipMalloc((void **)&h->ii_cptr_w, wbytes) == hipSuccess) {
                 h->ii_n_win = n_win;

@@ -49,6 +49,7 @@ int launch_merge_topk_f64(const double *part_scores, const int32_t *part_ids, in
                           float *out_scores, hipStream_t stream);
 int launch_item_sparse_topk(const ItemItemParams &p, int32_t *out_ids, float *out_scores, hipStream_t stream);
 int item_sparse_wave_windows(int n_items);
+int item_sparse_wave_stride(int n_win);      // entries per row of the per-window offset table
 int launch_count_long_segments(const uint32_t *cw, int64_t n_rows, int n_win, unsigned long long *count, hipStream_t s);
 int launch_build_win_ptr(const int64_t *cptr, int n_chunks, const int32_t *idx, int64_t n_rows, int n_win, uint32_t *cw, hipStream_t s);
 int item_sparse_pass_capacity();

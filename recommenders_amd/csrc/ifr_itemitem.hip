@@ -1014,6 +1014,11 @@ constexpr int SW_CAND = 96;                             // the list + pending ca
 constexpr int SW_MAXK = 32;                             // longest list of this kernel (longer ones: the workgroup kernel)
 constexpr int SW_EXL = 32;                              // exclusion row entries kept in LDS
 constexpr int SW_WAVES = 4;
+// the per-row table of entry offsets per window: T[SW_CW_LEAD + k] = offset of the row's first entry with column >= k * SW_WIN,
+// k clamped into [0, n_win] (so that offsets a few windows past the end read as empty segments without a clamp), rows
+// 16-byte aligned; the kernel reads two offsets per load
+constexpr int SW_CW_LEAD = 2, SW_CW_TAIL = 8;
+__host__ __device__ inline int sw_cw_stride(int n_win) { return (SW_CW_LEAD + n_win + 1 + SW_CW_TAIL + 3) & ~3; }
 
 struct SwLds {
     double tab[SW_WIN + 64];                            // + a dummy slot per lane
@@ -1070,25 +1075,35 @@ __global__ __launch_bounds__(64 * SW_WAVES, 4) void item_sparse_wave_kernel(Item
     const bool has_row = e < m;
     const int hj = has_row ? p.h_idx[hb + e] : 0;
     const double x = has_row ? ldexp((double)p.h_val[hb + e], p.fx_shift) : 0.0;
-    const uint32_t *const cw = p.cptr_w + (int64_t)hj * (n_win + 1);          // entry offsets of the row per window
+    const uint32_t *const cw = p.cptr_w + (int64_t)hj * sw_cw_stride(n_win) + SW_CW_LEAD;      // entry offsets of the row per window
     const uint32_t base32 = has_row ? (uint32_t)p.cptr[(int64_t)hj * (p.n_chunks + 1)] : 0u;    // the row's first entry (< 2^30 entries in all)
     const uint2 *const rp = p.m_pair;
-    struct Pre { uint2 ent[SW_PRE]; int first, end; };
+    // A lane's SW_PRE entries are CONTIGUOUS (lane l of a row takes entries [l * SW_PRE, (l + 1) * SW_PRE) of the segment)
+    // and arrive in two loads, 16 + 8 bytes: what a wave's load costs here is one cache-line look-up per row, whatever
+    // the bytes per lane, so three 8-byte loads per window were three look-ups per row.  (8-byte aligned 16-byte loads:
+    // global memory takes any dword alignment.)
+    static_assert(SW_PRE == 3, "the prefetch is one 16-byte + one 8-byte load");
+    typedef uint32_t u32x4_a8 __attribute__((ext_vector_type(4), aligned(8)));
+    struct Pre { uint2 ent[SW_PRE]; int first, end, more; };
     auto issue = [&](Pre &s, int qa, int qb) __attribute__((always_inline)) {
         const int last = max(qb - 1, 0);
-#pragma unroll
-        for (int t = 0; t < SW_PRE; ++t) s.ent[t] = rp[base32 + (uint32_t)min(qa + l + t * L, last)];
-        s.first = qa + l;
+        const uint2 *const src = rp + (base32 + (uint32_t)min(qa + l * SW_PRE, last));      // (reads past the segment / the array's end land in the pad)
+        const u32x4_a8 two = *reinterpret_cast<const u32x4_a8 *>(src);
+        s.ent[0] = make_uint2(two[0], two[1]);
+        s.ent[1] = make_uint2(two[2], two[3]);
+        s.ent[2] = src[2];
+        s.first = qa + l * SW_PRE;
         s.end = qb;
+        s.more = qa + SW_PRE * L + l;                     // this lane's first entry beyond the prefetch
     };
     auto consume = [&](const Pre &s, int colA) __attribute__((always_inline)) {
 #pragma unroll
         for (int t = 0; t < SW_PRE; ++t) {
-            const bool ok = s.first + t * L < s.end;
+            const bool ok = s.first + t < s.end;
             const double r = fma(x, (double)__uint_as_float(s.ent[t].y), SD_MAGIC) - SD_MAGIC;
             atomicAdd(&S.tab[ok ? (int)s.ent[t].x - colA : SW_WIN + lane], ok ? r : 0.0);
         }
-        for (int q = s.first + SW_PRE * L; q < s.end; q += L) {            // segments longer than the prefetch (rare)
+        for (int q = s.more; q < s.end; q += L) {            // segments longer than the prefetch (rare)
             const uint2 e2 = rp[base32 + (uint32_t)q];
             atomicAdd(&S.tab[(int)e2.x - colA], fma(x, (double)__uint_as_float(e2.y), SD_MAGIC) - SD_MAGIC);
         }
@@ -1144,17 +1159,16 @@ __global__ __launch_bounds__(64 * SW_WAVES, 4) void item_sparse_wave_kernel(Item
 
     Pre A, B;
     int b1 = has_row ? (int)cw[1] : 0;
-    uint32_t b2raw = cw[min(2, n_win)];
+    uint2 onext = *reinterpret_cast<const uint2 *>(cw + 2);      // offsets of windows 2 and 3: one 8-byte load per pair of windows
     issue(A, 0, b1);
     // The common window -- the list is full and no claimed sum beats its K-th -- is kept to the loads, the adds, the
     // exchanges and ONE vote; everything else (candidates, segments longer than the prefetch, the short list of the first
     // window, merges) sits behind that vote.
     double tau_eff = -INFINITY;                           // the K-th sum while the list is full, else -inf (every sum is a candidate)
-    auto window = [&](int c, const Pre &cur, Pre &nxt) __attribute__((always_inline)) {
+    auto window = [&](int c, const Pre &cur, Pre &nxt, uint32_t b2raw) __attribute__((always_inline)) {
         const int colA = c * SW_WIN;
         const int b2 = has_row ? (int)b2raw : 0;
         issue(nxt, b1, b2);                               // window c + 1 (an empty range past the last window)
-        b2raw = cw[min(c + 3, n_win)];
         consume(cur, colA);
         b1 = b2;
         // the window's sums are complete: the LDS performs one wave's operations in issue order, so the exchanges below
@@ -1165,15 +1179,15 @@ __global__ __launch_bounds__(64 * SW_WAVES, 4) void item_sparse_wave_kernel(Item
         double v[SW_PRE];
 #pragma unroll
         for (int t = 0; t < SW_PRE; ++t) {
-            const bool ok = cur.first + t * L < cur.end;
+            const bool ok = cur.first + t < cur.end;
             v[t] = claim(ok ? (int)cur.ent[t].x - colA : SW_WIN + lane);
         }
-        bool look = cur.first + SW_PRE * L < cur.end;     // a segment longer than the prefetch
+        bool look = cur.more < cur.end;                   // a segment longer than the prefetch
 #pragma unroll
         for (int t = 0; t < SW_PRE; ++t) look |= v[t] > tau_eff;
         if (__builtin_expect(__any(look) == 0, 1)) return;
         const bool full = cnt == K;
-        for (int q = cur.first + SW_PRE * L; __any(q < cur.end); q += L) {    // (wave-uniform trip count for the ballots)
+        for (int q = cur.more; __any(q < cur.end); q += L) {    // (wave-uniform trip count for the ballots)
             const bool in = q < cur.end;
             const int col = in ? (int)rp[base32 + (uint32_t)q].x : 0;
             const double vv = in ? claim(col - colA) : 0.0;
@@ -1212,8 +1226,10 @@ __global__ __launch_bounds__(64 * SW_WAVES, 4) void item_sparse_wave_kernel(Item
         tau_eff = cnt == K ? tau : -INFINITY;
     };
     for (int c = 0; c < n_win && !over; c += 2) {
-        window(c, A, B);
-        if (c + 1 < n_win && !over) window(c + 1, B, A);
+        const uint2 o = onext;                            // offsets of windows c + 2, c + 3 (requested two windows ago)
+        onext = *reinterpret_cast<const uint2 *>(cw + c + 4);
+        window(c, A, B, o.x);
+        if (c + 1 < n_win && !over) window(c + 1, B, A, o.y);
     }
     if (!over && nq > cnt) merge();
     // zero-sum columns (score 0 * col_scale) can still rank when the list is short or ends at or below zero: the sweep
@@ -1228,10 +1244,11 @@ __global__ __launch_bounds__(64 * SW_WAVES, 4) void item_sparse_wave_kernel(Item
 // entry offsets (from the row's first entry) of every row per SW_WIN-column window: [n_rows][n_win + 1]
 __global__ void build_win_ptr_kernel(const int64_t *cptr, int nc1, const int32_t *idx, int64_t n_rows, int n_win, uint32_t *cw)
 {
+    const int stride = sw_cw_stride(n_win);
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n_rows * (n_win + 1)) return;
-    const int64_t r = t / (n_win + 1);
-    const int c = (int)(t - r * (n_win + 1));
+    if (t >= n_rows * stride) return;
+    const int64_t r = t / stride;
+    const int c = min(max((int)(t - r * stride) - SW_CW_LEAD, 0), n_win);
     const int64_t b = cptr[r * nc1], e = cptr[r * nc1 + nc1 - 1];
     int64_t lo = b, hi = e;
     const int64_t target = (int64_t)c * SW_WIN;
@@ -1248,7 +1265,7 @@ __global__ void count_long_segments_kernel(const uint32_t *cw, int64_t n_rows, i
     if (t < n_rows * n_win) {
         const int64_t r = t / n_win;
         const int c = (int)(t - r * n_win);
-        const uint32_t *row = cw + r * (n_win + 1);
+        const uint32_t *row = cw + r * sw_cw_stride(n_win) + SW_CW_LEAD;
         is_long = row[c + 1] - row[c] > (uint32_t)SW_PRE;
     }
     const unsigned long long b = __ballot(is_long);
@@ -1264,10 +1281,11 @@ int launch_count_long_segments(const uint32_t *cw, int64_t n_rows, int n_win, un
 }
 
 int item_sparse_wave_windows(int n_items) { return (n_items + SW_WIN - 1) / SW_WIN; }
+int item_sparse_wave_stride(int n_win) { return sw_cw_stride(n_win); }
 
 int launch_build_win_ptr(const int64_t *cptr, int n_chunks, const int32_t *idx, int64_t n_rows, int n_win, uint32_t *cw, hipStream_t s)
 {
-    const int64_t total = n_rows * (n_win + 1);
+    const int64_t total = n_rows * sw_cw_stride(n_win);
     if (total <= 0) return 0;
     hipLaunchKernelGGL(build_win_ptr_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, cptr, n_chunks + 1, idx, n_rows, n_win, cw);
     return hipGetLastError() == hipSuccess ? 0 : -3;
