@@ -1159,7 +1159,8 @@ __global__ __launch_bounds__(64 * SW_WAVES, 4) void item_sparse_wave_kernel(Item
 
     Pre A, B;
     int b1 = has_row ? (int)cw[1] : 0;
-    uint2 onext = *reinterpret_cast<const uint2 *>(cw + 2);      // offsets of windows 2 and 3: one 8-byte load per pair of windows
+    typedef uint32_t u32x4_a8w __attribute__((ext_vector_type(4), aligned(8)));
+    u32x4_a8w onext = *reinterpret_cast<const u32x4_a8w *>(cw + 2);      // offsets of windows 2 ... 5: one 16-byte load per four windows
     issue(A, 0, b1);
     // The common window -- the list is full and no claimed sum beats its K-th -- is kept to the loads, the adds, the
     // exchanges and ONE vote; everything else (candidates, segments longer than the prefetch, the short list of the first
@@ -1225,11 +1226,13 @@ __global__ __launch_bounds__(64 * SW_WAVES, 4) void item_sparse_wave_kernel(Item
         if (!over && nq > cnt && (!full || nq - cnt >= SD_LAZY + K || nq + 24 > SW_CAND)) merge();   // lazy, like the kernel above
         tau_eff = cnt == K ? tau : -INFINITY;
     };
-    for (int c = 0; c < n_win && !over; c += 2) {
-        const uint2 o = onext;                            // offsets of windows c + 2, c + 3 (requested two windows ago)
-        onext = *reinterpret_cast<const uint2 *>(cw + c + 4);
-        window(c, A, B, o.x);
-        if (c + 1 < n_win && !over) window(c + 1, B, A, o.y);
+    for (int c = 0; c < n_win && !over; c += 4) {
+        const u32x4_a8w o = onext;                        // offsets of windows c + 2 ... c + 5 (requested four windows ago)
+        onext = *reinterpret_cast<const u32x4_a8w *>(cw + c + 6);
+        window(c, A, B, o[0]);
+        if (c + 1 < n_win && !over) window(c + 1, B, A, o[1]);
+        if (c + 2 < n_win && !over) window(c + 2, A, B, o[2]);
+        if (c + 3 < n_win && !over) window(c + 3, B, A, o[3]);
     }
     if (!over && nq > cnt) merge();
     // zero-sum columns (score 0 * col_scale) can still rank when the list is short or ends at or below zero: the sweep
