@@ -1084,30 +1084,6 @@ __global__ __launch_bounds__(64 * SW_WAVES, 4) void item_sparse_wave_kernel(Item
     // global memory takes any dword alignment.)
     static_assert(SW_PRE == 3, "the prefetch is one 16-byte + one 8-byte load");
     typedef uint32_t u32x4_a8 __attribute__((ext_vector_type(4), aligned(8)));
-    struct Pre { uint2 ent[SW_PRE]; int first, end, more; };
-    auto issue = [&](Pre &s, int qa, int qb) __attribute__((always_inline)) {
-        const int last = max(qb - 1, 0);
-        const uint2 *const src = rp + (base32 + (uint32_t)min(qa + l * SW_PRE, last));      // (reads past the segment / the array's end land in the pad)
-        const u32x4_a8 two = *reinterpret_cast<const u32x4_a8 *>(src);
-        s.ent[0] = make_uint2(two[0], two[1]);
-        s.ent[1] = make_uint2(two[2], two[3]);
-        s.ent[2] = src[2];
-        s.first = qa + l * SW_PRE;
-        s.end = qb;
-        s.more = qa + SW_PRE * L + l;                     // this lane's first entry beyond the prefetch
-    };
-    auto consume = [&](const Pre &s, int colA) __attribute__((always_inline)) {
-#pragma unroll
-        for (int t = 0; t < SW_PRE; ++t) {
-            const bool ok = s.first + t < s.end;
-            const double r = fma(x, (double)__uint_as_float(s.ent[t].y), SD_MAGIC) - SD_MAGIC;
-            atomicAdd(&S.tab[ok ? (int)s.ent[t].x - colA : SW_WIN + lane], ok ? r : 0.0);
-        }
-        for (int q = s.more; q < s.end; q += L) {            // segments longer than the prefetch (rare)
-            const uint2 e2 = rp[base32 + (uint32_t)q];
-            atomicAdd(&S.tab[(int)e2.x - colA], fma(x, (double)__uint_as_float(e2.y), SD_MAGIC) - SD_MAGIC);
-        }
-    };
     auto claim = [&](int slot) __attribute__((always_inline)) -> double {
         return __longlong_as_double((long long)atomicExch(reinterpret_cast<unsigned long long *>(&S.tab[slot]), 0ull));
     };
@@ -1157,6 +1133,37 @@ __global__ __launch_bounds__(64 * SW_WAVES, 4) void item_sparse_wave_kernel(Item
         tau = S.cv[K - 1];                                // (meaningful once cnt == K)
     };
 
+    // With two or more lanes per row (histories of at most 32 rows) a lane takes TWO entries -- the 16-byte load alone:
+    // 2 L >= 4 entries per segment -- and the 8-byte load is not issued at all (wave-uniform).
+    // Compiled twice (three = a lane per row / two entries per lane): a run-time flag inside the loop cost more than the load.
+    auto sweep = [&](auto three_t) __attribute__((always_inline)) {
+    constexpr bool three = decltype(three_t)::value;
+    constexpr int per = three ? SW_PRE : 2;
+    struct Pre { uint2 ent[SW_PRE]; int first, end, more; };
+    auto issue = [&](Pre &s, int qa, int qb) __attribute__((always_inline)) {
+        const int last = max(qb - 1, 0);
+        const uint2 *const src = rp + (base32 + (uint32_t)min(qa + l * per, last));      // (reads past the segment / the array's end land in the pad)
+        const u32x4_a8 two = *reinterpret_cast<const u32x4_a8 *>(src);
+        s.ent[0] = make_uint2(two[0], two[1]);
+        s.ent[1] = make_uint2(two[2], two[3]);
+        if (three) s.ent[2] = src[2]; else s.ent[2] = make_uint2(0u, 0u);
+        s.first = qa + l * per;
+        s.end = qb;
+        s.more = qa + per * L + l;                        // this lane's first entry beyond the prefetch
+    };
+    auto consume = [&](const Pre &s, int colA) __attribute__((always_inline)) {
+#pragma unroll
+        for (int t = 0; t < SW_PRE; ++t) {
+            if (t == 2 && !three) break;
+            const bool ok = s.first + t < s.end;
+            const double r = fma(x, (double)__uint_as_float(s.ent[t].y), SD_MAGIC) - SD_MAGIC;
+            atomicAdd(&S.tab[ok ? (int)s.ent[t].x - colA : SW_WIN + lane], ok ? r : 0.0);
+        }
+        for (int q = s.more; q < s.end; q += L) {            // segments longer than the prefetch (rare)
+            const uint2 e2 = rp[base32 + (uint32_t)q];
+            atomicAdd(&S.tab[(int)e2.x - colA], fma(x, (double)__uint_as_float(e2.y), SD_MAGIC) - SD_MAGIC);
+        }
+    };
     Pre A, B;
     int b1 = has_row ? (int)cw[1] : 0;
     typedef uint32_t u32x4_a8w __attribute__((ext_vector_type(4), aligned(8)));
@@ -1180,6 +1187,7 @@ __global__ __launch_bounds__(64 * SW_WAVES, 4) void item_sparse_wave_kernel(Item
         double v[SW_PRE];
 #pragma unroll
         for (int t = 0; t < SW_PRE; ++t) {
+            if (t == 2 && !three) { v[t] = 0.0; break; }
             const bool ok = cur.first + t < cur.end;
             v[t] = claim(ok ? (int)cur.ent[t].x - colA : SW_WIN + lane);
         }
@@ -1234,6 +1242,8 @@ __global__ __launch_bounds__(64 * SW_WAVES, 4) void item_sparse_wave_kernel(Item
         if (c + 2 < n_win && !over) window(c + 2, A, B, o[2]);
         if (c + 3 < n_win && !over) window(c + 3, B, A, o[3]);
     }
+    };
+    if (L == 1) sweep(std::true_type{}); else sweep(std::false_type{});
     if (!over && nq > cnt) merge();
     // zero-sum columns (score 0 * col_scale) can still rank when the list is short or ends at or below zero: the sweep
     // over them lives in the workgroup kernel
