@@ -786,9 +786,16 @@ __global__ __launch_bounds__(SD_BLOCK, 4) void item_sparse_topk_kernel(ItemItemP
                 const double r = fma(x, (double)__uint_as_float(s.ent[t].y), SD_MAGIC) - SD_MAGIC;
                 atomicAdd(&tab[ok ? (int)s.ent[t].x - colA : SP_CHUNK + lane], ok ? r : 0.0);
             }
-            for (int q = s.first + SD_PRE * L; q < s.end; q += L) {        // segments longer than the prefetch (rare)
-                const uint2 e2 = rp[base32 + (uint32_t)q];
-                atomicAdd(&tab[(int)e2.x - colA], fma(x, (double)__uint_as_float(e2.y), SD_MAGIC) - SD_MAGIC);
+            // segments longer than the prefetch (histories beyond 85 rows leave a row one or two lanes: 3 or 6 of its ~8
+            // entries per window): three loads in flight per round trip, not one
+            for (int q = s.first + SD_PRE * L; q < s.end; q += SD_PRE * L) {
+                const int last = s.end - 1;
+                uint2 e2[SD_PRE];
+#pragma unroll
+                for (int t = 0; t < SD_PRE; ++t) e2[t] = rp[base32 + (uint32_t)min(q + t * L, last)];
+#pragma unroll
+                for (int t = 0; t < SD_PRE; ++t)
+                    if (q + t * L < s.end) atomicAdd(&tab[(int)e2[t].x - colA], fma(x, (double)__uint_as_float(e2[t].y), SD_MAGIC) - SD_MAGIC);
             }
         };
         // (only the LOW 32 bits of an entry position are loaded: the difference to the row's first entry fits, and a 64-bit
@@ -829,10 +836,17 @@ __global__ __launch_bounds__(SD_BLOCK, 4) void item_sparse_topk_kernel(ItemItemP
                 const bool ok = s.first + t * L < s.end;
                 v[t] = claim(ok ? (int)s.ent[t].x - colA : SP_CHUNK + lane);
             }
-            for (int q = s.first + SD_PRE * L; q < s.end; q += L) {        // segments longer than the prefetch (rare)
-                const int col = (int)rp[base32 + (uint32_t)q].x;
-                const double vv = claim(col - colA);
-                if (vv != 0.0 && (!full || vv > tau)) append(vv, col);      // (exclusions: looked up at the merge)
+            for (int q = s.first + SD_PRE * L; q < s.end; q += SD_PRE * L) {        // segments longer than the prefetch
+                const int last = s.end - 1;
+                int col[SD_PRE];
+#pragma unroll
+                for (int t = 0; t < SD_PRE; ++t) col[t] = (int)rp[base32 + (uint32_t)min(q + t * L, last)].x;
+#pragma unroll
+                for (int t = 0; t < SD_PRE; ++t) {
+                    if (q + t * L >= s.end) break;
+                    const double vv = claim(col[t] - colA);
+                    if (vv != 0.0 && (!full || vv > tau)) append(vv, col[t]);      // (exclusions: looked up at the merge)
+                }
             }
             if (full) {
                 bool any = false;                         // (a zero passes when the K-th sum is negative: sorted out inside)
