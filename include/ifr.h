@@ -59,7 +59,7 @@ const char *ifr_last_error(ifr_handle h);
  * "wide_chunk_cap", "wide_stats": tuning / statistics of that path; "item_f64": see ifr_fit_ease (none of these
  * changes a result);
  * "csr_wave": CSR top-K kernel choice -- 0 = the workgroup-per-user kernel only; 1 (default) = one wave per user where
- * the history has at most 64 rows (the rest handed to the workgroup kernel), IF at most 1 % of the matrix's (row,
+ * the history has at most 128 rows (the rest handed to the workgroup kernel), IF at most 1 % of the matrix's (row,
  * 1024-column window) segments hold more than the three entries that kernel prefetches (measured when the matrix is
  * set: evenly spread rows; on matrices with uniformly drawn columns the workgroup kernel is the faster one); 2 = force
  * the wave kernel (tests).  Same results either way;
@@ -201,7 +201,7 @@ int ifr_read_eval_csr(ifr_handle h, int which, int64_t *indptr, int32_t *indices
  * ascending on ties.  out_ids/out_scores: dev [n][K]; unfilled slots (fewer than K
  * candidates) hold id -1 / score -inf.  user_ids: dev [n].
  * 1 <= K <= IFR_MAX_TOPK for dot-product models, IFR_MAX_TOPK_ITEM for dense item matrices, IFR_MAX_TOPK_ITEM_CSR for
- * CSR item matrices (K <= 32: histories of at most 64 rows by the wave-per-user kernel where the matrix suits it, see
+ * CSR item matrices (K <= 32: histories of at most 128 rows by the wave-per-user kernel where the matrix suits it, see
  * "csr_wave"; everything else by the workgroup-per-user kernel).  Dot-product models, K <= 16: lane-private
  * sorted lists, merged per user; the call is asynchronous on `stream`.  16 < K <= 100 (dot-product models): the same
  * kernel; a user's two 16-entry lists per item chunk (2 ... 8 chunks, about K / 12) hold the top K unless more than

@@ -1014,20 +1014,23 @@ __global__ __launch_bounds__(SD_BLOCK, 4) void item_sparse_topk_kernel(ItemItemP
 // The same sweep with ONE WAVE per user (round 3, last step): the workgroup-per-user kernel above spends its time in a
 // dependent chain per window -- adds, LDS drain, barrier, exchanges, barrier, counter read -- that only the four
 // workgroups a CU holds can overlap, and all four waves of a workgroup execute the same scalar bookkeeping.  A user
-// with at most 64 history rows needs neither: a wave keeps a row per lane, a private table of 1 024 direct-mapped fp64
-// accumulators (8 KB) and its candidate buffer; nothing crosses waves, so there is no s_barrier and no shared counter
-// -- candidate slots come from a ballot prefix -- and a CU holds 16 independent users.  Arithmetic, exchange-claim
-// selection, lazy merges and the exact-domain ranking are those of the kernel above (same results bit for bit).
-// What this kernel does not serve it hands to the workgroup kernel through p.long_list: histories beyond 64 rows,
+// with at most 128 history rows needs neither: a wave keeps a row (65 ... 128 rows: two) per lane, a private table of
+// 1 024 direct-mapped fp64 accumulators (8 KB) and its candidate buffer; nothing crosses waves, so there is no s_barrier
+// and no shared counter -- candidate slots come from a ballot prefix -- and a CU holds 16 independent users, each a
+// workgroup of its own (with four users per workgroup the LDS of three finished waves waited for the slowest: K = 32
+// 17 % slower).  Arithmetic, exchange-claim selection, lazy merges and the exact-domain ranking are those of the kernel
+// above (same results bit for bit).
+// What this kernel does not serve it hands to the workgroup kernel through p.long_list: histories beyond 128 rows,
 // users whose list ends short or with a K-th sum <= 0 (zero-sum columns may rank: the sweep over them lives there),
 // and a candidate buffer that overflows (mass ties).
 // ------------------------------------------------------------------------------------
 constexpr int SW_WIN = 1024;                            // columns per window
 constexpr int SW_PRE = 3;                               // entries per lane prefetched one window ahead
 constexpr int SW_CAND = 96;                             // the list + pending candidates
+constexpr int SW_ROWS = 2;                              // history rows per lane, at most (histories of up to 128 rows)
 constexpr int SW_MAXK = 32;                             // longest list of this kernel (longer ones: the workgroup kernel)
 constexpr int SW_EXL = 32;                              // exclusion row entries kept in LDS
-constexpr int SW_WAVES = 4;
+constexpr int SW_WAVES = 1;                             // users (waves) per workgroup
 // the per-row table of entry offsets per window: T[SW_CW_LEAD + k] = offset of the row's first entry with column >= k * SW_WIN,
 // k clamped into [0, n_win] (so that offsets a few windows past the end read as empty segments without a clamp), rows
 // 16-byte aligned; the kernel reads two offsets per load
@@ -1051,7 +1054,7 @@ __device__ __forceinline__ void sw_lds_order()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
 }
 
-__global__ __launch_bounds__(64 * SW_WAVES, 4) void item_sparse_wave_kernel(ItemItemParams p, int32_t *out_ids, float *out_scores)
+__global__ __launch_bounds__(64 * SW_WAVES) __attribute__((amdgpu_waves_per_eu(4, 4))) void item_sparse_wave_kernel(ItemItemParams p, int32_t *out_ids, float *out_scores)
 {
     __shared__ __attribute__((aligned(16))) SwLds lds[SW_WAVES];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1071,7 +1074,7 @@ __global__ __launch_bounds__(64 * SW_WAVES, 4) void item_sparse_wave_kernel(Item
     auto hand_over = [&]() __attribute__((always_inline)) {
         if (lane == 0) p.long_list[atomicAdd(p.long_cnt, 1)] = (int32_t)i;
     };
-    if (he - hb > 64 || he == hb) { hand_over(); return; }      // (no history: only zero-sum columns to rank)
+    if (he - hb > 64 * SW_ROWS || he == hb) { hand_over(); return; }      // (no history: only zero-sum columns to rank)
     const int m = (int)(he - hb);
 
     for (int w = lane; w < SW_WIN + 64; w += 64) S.tab[w] = 0.0;
@@ -1083,14 +1086,10 @@ __global__ __launch_bounds__(64 * SW_WAVES, 4) void item_sparse_wave_kernel(Item
         return lo < n_ex && (ex_lds ? S.exl[lo] : p.ex_idx[eb + lo]) == col;
     };
 
-    // a lane keeps ONE history row for the whole sweep: L lanes share a row's segment of a window
+    // a lane keeps ONE history row for the whole sweep (L lanes share a row's segment of a window) -- or, histories of
+    // 65 ... 128 rows, TWO rows (lane and lane + 64)
     const int L = max(1, 64 / max(m, 1));
     const int e = lane / L, l = lane - e * L;
-    const bool has_row = e < m;
-    const int hj = has_row ? p.h_idx[hb + e] : 0;
-    const double x = has_row ? ldexp((double)p.h_val[hb + e], p.fx_shift) : 0.0;
-    const uint32_t *const cw = p.cptr_w + (int64_t)hj * sw_cw_stride(n_win) + SW_CW_LEAD;      // entry offsets of the row per window
-    const uint32_t base32 = has_row ? (uint32_t)p.cptr[(int64_t)hj * (p.n_chunks + 1)] : 0u;    // the row's first entry (< 2^30 entries in all)
     const uint2 *const rp = p.m_pair;
     // A lane's SW_PRE entries are CONTIGUOUS (lane l of a row takes entries [l * SW_PRE, (l + 1) * SW_PRE) of the segment)
     // and arrive in two loads, 16 + 8 bytes: what a wave's load costs here is one cache-line look-up per row, whatever
@@ -1147,117 +1146,174 @@ __global__ __launch_bounds__(64 * SW_WAVES, 4) void item_sparse_wave_kernel(Item
         tau = S.cv[K - 1];                                // (meaningful once cnt == K)
     };
 
-    // With two or more lanes per row (histories of at most 32 rows) a lane takes TWO entries -- the 16-byte load alone:
-    // 2 L >= 4 entries per segment -- and the 8-byte load is not issued at all (wave-uniform).
-    // Compiled twice (three = a lane per row / two entries per lane): a run-time flag inside the loop cost more than the load.
-    auto sweep = [&](auto three_t) __attribute__((always_inline)) {
+    // The sweep is compiled three times (a run-time flag inside the loop cost more than the load it saved):
+    //   two or more lanes per row (histories of at most 32 rows): a lane takes TWO entries -- the 16-byte load alone,
+    //     2 L >= 4 entries per segment;
+    //   a lane per row (33 ... 64 rows): three entries, 16 + 8 bytes;
+    //   two rows per lane (65 ... 128 rows: rows lane and lane + 64), three entries each.
+    auto sweep = [&](auto three_t, auto rows_t) __attribute__((always_inline)) {
     constexpr bool three = decltype(three_t)::value;
+    constexpr int ROWS = decltype(rows_t)::value;
     constexpr int per = three ? SW_PRE : 2;
-    struct Pre { uint2 ent[SW_PRE]; int first, end, more; };
-    auto issue = [&](Pre &s, int qa, int qb) __attribute__((always_inline)) {
-        const int last = max(qb - 1, 0);
-        const uint2 *const src = rp + (base32 + (uint32_t)min(qa + l * per, last));      // (reads past the segment / the array's end land in the pad)
-        const u32x4_a8 two = *reinterpret_cast<const u32x4_a8 *>(src);
-        s.ent[0] = make_uint2(two[0], two[1]);
-        s.ent[1] = make_uint2(two[2], two[3]);
-        if (three) s.ent[2] = src[2]; else s.ent[2] = make_uint2(0u, 0u);
-        s.first = qa + l * per;
-        s.end = qb;
-        s.more = qa + per * L + l;                        // this lane's first entry beyond the prefetch
+    bool has_row[ROWS];
+    double x[ROWS];
+    const uint32_t *cw[ROWS];
+    uint32_t base32[ROWS];
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+        const int er = e + 64 * r;
+        has_row[r] = er < m;
+        const int hj = has_row[r] ? p.h_idx[hb + er] : 0;
+        x[r] = has_row[r] ? ldexp((double)p.h_val[hb + er], p.fx_shift) : 0.0;
+        cw[r] = p.cptr_w + (int64_t)hj * sw_cw_stride(n_win) + SW_CW_LEAD;                           // entry offsets of the row per window
+        base32[r] = has_row[r] ? (uint32_t)p.cptr[(int64_t)hj * (p.n_chunks + 1)] : 0u;             // the row's first entry (< 2^30 entries in all)
+    }
+    struct Pre { uint2 ent[ROWS][SW_PRE]; int first[ROWS], end[ROWS], more[ROWS]; };
+    auto issue = [&](Pre &s, const int *qa, const int *qb) __attribute__((always_inline)) {
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+            const int last = max(qb[r] - 1, 0);
+            const uint2 *const src = rp + (base32[r] + (uint32_t)min(qa[r] + l * per, last));      // (reads past the segment / the array's end land in the pad)
+            const u32x4_a8 two = *reinterpret_cast<const u32x4_a8 *>(src);
+            s.ent[r][0] = make_uint2(two[0], two[1]);
+            s.ent[r][1] = make_uint2(two[2], two[3]);
+            if (three) s.ent[r][2] = src[2]; else s.ent[r][2] = make_uint2(0u, 0u);
+            s.first[r] = qa[r] + l * per;
+            s.end[r] = qb[r];
+            s.more[r] = qa[r] + per * L + l;              // this lane's first entry beyond the prefetch
+        }
     };
     auto consume = [&](const Pre &s, int colA) __attribute__((always_inline)) {
 #pragma unroll
-        for (int t = 0; t < SW_PRE; ++t) {
-            if (t == 2 && !three) break;
-            const bool ok = s.first + t < s.end;
-            const double r = fma(x, (double)__uint_as_float(s.ent[t].y), SD_MAGIC) - SD_MAGIC;
-            atomicAdd(&S.tab[ok ? (int)s.ent[t].x - colA : SW_WIN + lane], ok ? r : 0.0);
+        for (int r = 0; r < ROWS; ++r) {
+#pragma unroll
+            for (int t = 0; t < SW_PRE; ++t) {
+                if (t == 2 && !three) break;
+                const bool ok = s.first[r] + t < s.end[r];
+                const double a = fma(x[r], (double)__uint_as_float(s.ent[r][t].y), SD_MAGIC) - SD_MAGIC;
+                atomicAdd(&S.tab[ok ? (int)s.ent[r][t].x - colA : SW_WIN + lane], ok ? a : 0.0);
+            }
         }
-        for (int q = s.more; q < s.end; q += L) {            // segments longer than the prefetch (rare)
-            const uint2 e2 = rp[base32 + (uint32_t)q];
-            atomicAdd(&S.tab[(int)e2.x - colA], fma(x, (double)__uint_as_float(e2.y), SD_MAGIC) - SD_MAGIC);
-        }
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r)
+            for (int q = s.more[r]; q < s.end[r]; q += L) {            // segments longer than the prefetch (rare)
+                const uint2 e2 = rp[base32[r] + (uint32_t)q];
+                atomicAdd(&S.tab[(int)e2.x - colA], fma(x[r], (double)__uint_as_float(e2.y), SD_MAGIC) - SD_MAGIC);
+            }
     };
     Pre A, B;
-    int b1 = has_row ? (int)cw[1] : 0;
+    int b1[ROWS];
     typedef uint32_t u32x4_a8w __attribute__((ext_vector_type(4), aligned(8)));
-    u32x4_a8w onext = *reinterpret_cast<const u32x4_a8w *>(cw + 2);      // offsets of windows 2 ... 5: one 16-byte load per four windows
-    issue(A, 0, b1);
+    u32x4_a8w onext[ROWS];                                // offsets of windows 2 ... 5: one 16-byte load per four windows and row
+    {
+        int zero[ROWS];
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+            b1[r] = has_row[r] ? (int)cw[r][1] : 0;
+            onext[r] = *reinterpret_cast<const u32x4_a8w *>(cw[r] + 2);
+            zero[r] = 0;
+        }
+        issue(A, zero, b1);
+    }
     // The common window -- the list is full and no claimed sum beats its K-th -- is kept to the loads, the adds, the
     // exchanges and ONE vote; everything else (candidates, segments longer than the prefetch, the short list of the first
     // window, merges) sits behind that vote.
     double tau_eff = -INFINITY;                           // the K-th sum while the list is full, else -inf (every sum is a candidate)
-    auto window = [&](int c, const Pre &cur, Pre &nxt, uint32_t b2raw) __attribute__((always_inline)) {
+    auto window = [&](int c, const Pre &cur, Pre &nxt, const u32x4_a8w *o, int oi) __attribute__((always_inline)) {
         const int colA = c * SW_WIN;
-        const int b2 = has_row ? (int)b2raw : 0;
+        int b2[ROWS];
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) b2[r] = has_row[r] ? (int)o[r][oi] : 0;
         issue(nxt, b1, b2);                               // window c + 1 (an empty range past the last window)
         consume(cur, colA);
-        b1 = b2;
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) b1[r] = b2[r];
         // the window's sums are complete: the LDS performs one wave's operations in issue order, so the exchanges below
         // find every lane's adds without waiting for them (only the compiler must keep the order)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
-        double v[SW_PRE];
+        double v[ROWS][SW_PRE];
+        bool look = false;
 #pragma unroll
-        for (int t = 0; t < SW_PRE; ++t) {
-            if (t == 2 && !three) { v[t] = 0.0; break; }
-            const bool ok = cur.first + t < cur.end;
-            v[t] = claim(ok ? (int)cur.ent[t].x - colA : SW_WIN + lane);
+        for (int r = 0; r < ROWS; ++r) {
+#pragma unroll
+            for (int t = 0; t < SW_PRE; ++t) {
+                if (t == 2 && !three) { v[r][t] = 0.0; break; }
+                const bool ok = cur.first[r] + t < cur.end[r];
+                v[r][t] = claim(ok ? (int)cur.ent[r][t].x - colA : SW_WIN + lane);
+            }
+            look |= cur.more[r] < cur.end[r];             // a segment longer than the prefetch
         }
-        bool look = cur.more < cur.end;                   // a segment longer than the prefetch
 #pragma unroll
-        for (int t = 0; t < SW_PRE; ++t) look |= v[t] > tau_eff;
+        for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+            for (int t = 0; t < SW_PRE; ++t) look |= v[r][t] > tau_eff;
         if (__builtin_expect(__any(look) == 0, 1)) return;
         const bool full = cnt == K;
-        for (int q = cur.more; __any(q < cur.end); q += L) {    // (wave-uniform trip count for the ballots)
-            const bool in = q < cur.end;
-            const int col = in ? (int)rp[base32 + (uint32_t)q].x : 0;
-            const double vv = in ? claim(col - colA) : 0.0;
-            append(in && vv != 0.0 && (!full || vv > tau), vv, col);
-        }
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r)
+            for (int q = cur.more[r]; __any(q < cur.end[r]); q += L) {    // (wave-uniform trip count for the ballots)
+                const bool in = q < cur.end[r];
+                const int col = in ? (int)rp[base32[r] + (uint32_t)q].x : 0;
+                const double vv = in ? claim(col - colA) : 0.0;
+                append(in && vv != 0.0 && (!full || vv > tau), vv, col);
+            }
         if (full) {
 #pragma unroll
-            for (int t = 0; t < SW_PRE; ++t) append(v[t] != 0.0 && v[t] > tau, v[t], (int)cur.ent[t].x);   // (a zero passes the vote when the K-th sum is negative)
+            for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+                for (int t = 0; t < SW_PRE; ++t) append(v[r][t] != 0.0 && v[r][t] > tau, v[r][t], (int)cur.ent[r][t].x);   // (a zero passes the vote when the K-th sum is negative)
         } else if ([&]() { bool nz = false;
 #pragma unroll
-                           for (int t = 0; t < SW_PRE; ++t) nz |= v[t] != 0.0;
+                           for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+                               for (int t = 0; t < SW_PRE; ++t) nz |= v[r][t] != 0.0;
                            return __any(nz) != 0; }()) {
             // short list: a lower bound of the window's K-th best sum by a bit-by-bit search over the order-preserving
             // high words of ALL claimed sums (ballot + popcount; excluded columns are looked up first)
-            uint32_t key[SW_PRE];
+            uint32_t key[ROWS][SW_PRE];
 #pragma unroll
-            for (int t = 0; t < SW_PRE; ++t) {
-                if (v[t] != 0.0 && n_ex != 0 && excluded((int)cur.ent[t].x)) v[t] = 0.0;
-                const uint32_t hi = (uint32_t)__double2hiint(v[t]);
-                key[t] = v[t] != 0.0 ? (hi ^ ((uint32_t)((int32_t)hi >> 31) | 0x80000000u)) : 0u;
-            }
+            for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+                for (int t = 0; t < SW_PRE; ++t) {
+                    if (v[r][t] != 0.0 && n_ex != 0 && excluded((int)cur.ent[r][t].x)) v[r][t] = 0.0;
+                    const uint32_t hi = (uint32_t)__double2hiint(v[r][t]);
+                    key[r][t] = v[r][t] != 0.0 ? (hi ^ ((uint32_t)((int32_t)hi >> 31) | 0x80000000u)) : 0u;
+                }
             uint32_t fl = 0;
 #pragma unroll
             for (int b = 31; b > 31 - SD_FLOOR_BITS; --b) {
                 const uint32_t trial = fl | (1u << b);
                 int n_at = 0;
 #pragma unroll
-                for (int t = 0; t < SW_PRE; ++t) n_at += __popcll(__ballot(key[t] >= trial));
+                for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+                    for (int t = 0; t < SW_PRE; ++t) n_at += __popcll(__ballot(key[r][t] >= trial));
                 if (n_at >= K) fl = trial;
             }
             const uint32_t floor_k = max(fl, 1u);
 #pragma unroll
-            for (int t = 0; t < SW_PRE; ++t) append(key[t] >= floor_k, v[t], (int)cur.ent[t].x);
+            for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+                for (int t = 0; t < SW_PRE; ++t) append(key[r][t] >= floor_k, v[r][t], (int)cur.ent[r][t].x);
         }
         if (!over && nq > cnt && (!full || nq - cnt >= SD_LAZY + K || nq + 24 > SW_CAND)) merge();   // lazy, like the kernel above
         tau_eff = cnt == K ? tau : -INFINITY;
     };
     for (int c = 0; c < n_win && !over; c += 4) {
-        const u32x4_a8w o = onext;                        // offsets of windows c + 2 ... c + 5 (requested four windows ago)
-        onext = *reinterpret_cast<const u32x4_a8w *>(cw + c + 6);
-        window(c, A, B, o[0]);
-        if (c + 1 < n_win && !over) window(c + 1, B, A, o[1]);
-        if (c + 2 < n_win && !over) window(c + 2, A, B, o[2]);
-        if (c + 3 < n_win && !over) window(c + 3, B, A, o[3]);
+        u32x4_a8w o[ROWS];                                // offsets of windows c + 2 ... c + 5 (requested four windows ago)
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) { o[r] = onext[r]; onext[r] = *reinterpret_cast<const u32x4_a8w *>(cw[r] + c + 6); }
+        window(c, A, B, o, 0);
+        if (c + 1 < n_win && !over) window(c + 1, B, A, o, 1);
+        if (c + 2 < n_win && !over) window(c + 2, A, B, o, 2);
+        if (c + 3 < n_win && !over) window(c + 3, B, A, o, 3);
     }
     };
-    if (L == 1) sweep(std::true_type{}); else sweep(std::false_type{});
+    if (m > 64) sweep(std::true_type{}, std::integral_constant<int, 2>{});
+    else if (L == 1) sweep(std::true_type{}, std::integral_constant<int, 1>{});
+    else sweep(std::false_type{}, std::integral_constant<int, 1>{});
     if (!over && nq > cnt) merge();
     // zero-sum columns (score 0 * col_scale) can still rank when the list is short or ends at or below zero: the sweep
     // over them lives in the workgroup kernel
