@@ -24,7 +24,7 @@ m_ptr = np.arange(ni + 1, dtype=np.int64) * nnz
 m_val = w["m_val"]
 users = np.arange(nu, dtype=np.int32)
 for name, idx in (("stratified", w["m_idx"]), ("uniform", m_idx)):
-    for wave in (1, 0):
+    for wave in (1, 0, 2):
         sc = HipScorer(0)
         sc.set_item_matrix_csr(m_ptr, idx, m_val, ni, w["col_scale"])
         sc.set_history_csr(w["h_ptr"], w["h_idx"], w["h_val"])
