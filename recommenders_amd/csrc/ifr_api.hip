@@ -83,6 +83,7 @@ struct ifr_handle_s {
     int64_t *ii_cptr = nullptr; int32_t *ii_idx = nullptr; float *ii_val = nullptr; int64_t ii_nnz = 0;
     uint2 *ii_pair = nullptr;    // CSR entries as interleaved (column, value) pairs: what the CSR top-K kernel streams
     double ii_long_frac = 0.0;   // share of (row, 1024-column window) segments longer than that kernel's prefetch
+    void *ii_win = nullptr;                            // 16-byte window words of the wave-per-user kernel, or null
     uint32_t *ii_cptr_w = nullptr; int ii_n_win = 0;   // entry offsets per 1024-column window (wave-per-user CSR top-K kernel), or null
     void *ws_long = nullptr; size_t ws_long_bytes = 0;  // users that kernel hands over: [0] = count, then the list
     int opt_csr_wave = 1;        // 0: CSR top-K by the workgroup-per-user kernel only
@@ -302,7 +303,7 @@ int64_t catalogue_items(ifr_handle h) { return h->opt_catalogue > h->n_items ? h
 
 void clear_item_model(ifr_handle h)
 {
-    dfree(h->iiM); dfree(h->iiM64); dfree(h->ii_cptr); dfree(h->ii_idx); dfree(h->ii_val); dfree(h->ii_pen); dfree(h->ii_pair); dfree(h->ii_cptr_w); h->ii_n_win = 0;
+    dfree(h->iiM); dfree(h->iiM64); dfree(h->ii_cptr); dfree(h->ii_idx); dfree(h->ii_val); dfree(h->ii_pen); dfree(h->ii_pair); dfree(h->ii_cptr_w); dfree(h->ii_win); h->ii_n_win = 0;
     dfree(h->hs_ptr); dfree(h->hs_idx); dfree(h->hs_val);
     h->ii_ld = 0; h->ii_nnz = 0; h->ii_chunks = 0; h->ii_maxabs = 0.f;
     h->hs_rows = 0; h->hs_nnz = 0; h->hs_l1max = 0.f;
@@ -395,7 +396,7 @@ int ifr_destroy(ifr_handle h)
     dfree(h->U); dfree(h->V); dfree(h->ibase); dfree(h->ubase);
     dfree(h->ex_ptr); dfree(h->ex_idx); dfree(h->ex_cnt); dfree(h->ex_pair);
     dfree(h->tr_ptr); dfree(h->tr_idx); dfree(h->discount);
-    dfree(h->iiM); dfree(h->iiM64); dfree(h->ii_cptr); dfree(h->ii_idx); dfree(h->ii_val); dfree(h->ii_pen); dfree(h->ii_pair); dfree(h->ii_cptr_w); h->ii_n_win = 0;
+    dfree(h->iiM); dfree(h->iiM64); dfree(h->ii_cptr); dfree(h->ii_idx); dfree(h->ii_val); dfree(h->ii_pen); dfree(h->ii_pair); dfree(h->ii_cptr_w); dfree(h->ii_win); h->ii_n_win = 0;
     dfree(h->hs_ptr); dfree(h->hs_idx); dfree(h->hs_val);
     dfree(h->ws_part); dfree(h->ws_met); dfree(h->ws_sort); dfree(h->ws_long);
     ifr::ease_release(&h->rocblas);
@@ -816,6 +817,13 @@ int ifr_set_item_matrix_csr(ifr_handle h, const int64_t *indptr, const int32_t *
                 if (!lrc && hipMemcpy(&n_long, d_long, sizeof(n_long), hipMemcpyDeviceToHost) != hipSuccess) lrc = -3;
                 dfree(d_long);
                 h->ii_long_frac = (double)n_long / std::max<double>(1.0, (double)n_items * n_win);
+                // the window words that kernel reads (one 16-byte word per row and window): where they stay within twice
+                // the entries' own bytes (or 256 MB) and 4 GB
+                const size_t win_bytes = (size_t)16 * (size_t)n_items * (size_t)n_win;
+                const size_t pair_bytes = sizeof(uint2) * (size_t)(nnz + ifr::item_csr_pad());
+                if (!lrc && win_bytes <= std::max<size_t>((size_t)256 << 20, 2 * pair_bytes) && win_bytes <= ((size_t)4 << 30) &&
+                    hipMalloc(&h->ii_win, win_bytes) == hipSuccess)
+                    lrc = ifr::launch_build_win_words(h->ii_cptr_w, h->ii_cptr, n_chunks, (const uint2 *)h->ii_pair, n_items, n_win, h->ii_win, 0);
             }
         }
     }
@@ -983,10 +991,10 @@ static int rank_topk_item_item(ifr_handle h, const int32_t *user_ids, int64_t n,
     p.K = K; p.KL = KL;
     std::pair<hipEvent_t, hipEvent_t> ev;
     if (h->mode == MODE_ITEM_CSR) {                  // one workgroup per user, final lists written directly
-        if (h->ii_cptr_w != nullptr && (h->opt_csr_wave == 2 || (h->opt_csr_wave == 1 && h->ii_long_frac <= 0.01))) {
+        if (h->ii_cptr_w != nullptr && h->ii_win != nullptr && (h->opt_csr_wave == 2 || (h->opt_csr_wave == 1 && h->ii_long_frac <= 0.01))) {
             rc = grow(h, &h->ws_long, &h->ws_long_bytes, sizeof(int32_t) * ((size_t)n + 1));
             if (rc) return rc;
-            p.cptr_w = h->ii_cptr_w; p.n_win = h->ii_n_win;
+            p.cptr_w = h->ii_cptr_w; p.n_win = h->ii_n_win; p.m_win = h->ii_win;
             p.long_cnt = (int *)h->ws_long; p.long_list = (int32_t *)h->ws_long + 1;
         }
         rc = prof_begin(h, s, &ev);

@@ -1086,17 +1086,17 @@ __global__ __launch_bounds__(64 * SW_WAVES) __attribute__((amdgpu_waves_per_eu(4
         return lo < n_ex && (ex_lds ? S.exl[lo] : p.ex_idx[eb + lo]) == col;
     };
 
-    // a lane keeps ONE history row for the whole sweep (L lanes share a row's segment of a window) -- or, histories of
-    // 65 ... 128 rows, TWO rows (lane and lane + 64)
-    const int L = max(1, 64 / max(m, 1));
-    const int e = lane / L, l = lane - e * L;
+    // A lane keeps ONE history row for the whole sweep -- or two / four rows (lane, lane + 64, ...: histories of up to 256
+    // rows).  The row's entries come from the WINDOW WORDS (m_win, built at set time): one 16-byte word per (row, window)
+    // that packs up to three entries -- three fp32 values + 3 x 10 bits of column inside the window + a 2-bit count --
+    // so a window costs a lane ONE load at an address that is a plain stride (no entry offsets to fetch first).  What a
+    // wave's load costs here is the cache-line look-up per lane, not the bytes: 8-byte entries took three loads + an
+    // offset load per window, then a 16-byte + an 8-byte load + a quarter of an offset load (20.7 -> 24.4 M users/s at
+    // C5), now one.  A segment with more than three entries is marked in its word (count 3 with the second and third
+    // column swapped -- their order does not matter to a sum) and its other entries are read from the pair array.
     const uint2 *const rp = p.m_pair;
-    // A lane's SW_PRE entries are CONTIGUOUS (lane l of a row takes entries [l * SW_PRE, (l + 1) * SW_PRE) of the segment)
-    // and arrive in two loads, 16 + 8 bytes: what a wave's load costs here is one cache-line look-up per row, whatever
-    // the bytes per lane, so three 8-byte loads per window were three look-ups per row.  (8-byte aligned 16-byte loads:
-    // global memory takes any dword alignment.)
-    static_assert(SW_PRE == 3, "the prefetch is one 16-byte + one 8-byte load");
-    typedef uint32_t u32x4_a8 __attribute__((ext_vector_type(4), aligned(8)));
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4 *const mw = reinterpret_cast<const u32x4 *>(p.m_win);
     auto claim = [&](int slot) __attribute__((always_inline)) -> double {
         return __longlong_as_double((long long)atomicExch(reinterpret_cast<unsigned long long *>(&S.tab[slot]), 0ull));
     };
@@ -1146,138 +1146,127 @@ __global__ __launch_bounds__(64 * SW_WAVES) __attribute__((amdgpu_waves_per_eu(4
         tau = S.cv[K - 1];                                // (meaningful once cnt == K)
     };
 
-    // The sweep is compiled three times (a run-time flag inside the loop cost more than the load it saved):
-    //   two or more lanes per row (histories of at most 32 rows): a lane takes TWO entries -- the 16-byte load alone,
-    //     2 L >= 4 entries per segment;
-    //   a lane per row (33 ... 64 rows): three entries, 16 + 8 bytes;
-    //   two rows per lane (65 ... 128 rows: rows lane and lane + 64), three entries each.
-    auto sweep = [&](auto three_t, auto rows_t) __attribute__((always_inline)) {
-    constexpr bool three = decltype(three_t)::value;
+    // compiled for one, two and four rows per lane
+    auto sweep = [&](auto rows_t) __attribute__((always_inline)) {
     constexpr int ROWS = decltype(rows_t)::value;
-    constexpr int per = three ? SW_PRE : 2;
     bool has_row[ROWS];
     double x[ROWS];
-    const uint32_t *cw[ROWS];
-    uint32_t base32[ROWS];
+    int hj[ROWS];
 #pragma unroll
     for (int r = 0; r < ROWS; ++r) {
-        const int er = e + 64 * r;
+        const int er = lane + 64 * r;
         has_row[r] = er < m;
-        const int hj = has_row[r] ? p.h_idx[hb + er] : 0;
+        hj[r] = has_row[r] ? p.h_idx[hb + er] : 0;
         x[r] = has_row[r] ? ldexp((double)p.h_val[hb + er], p.fx_shift) : 0.0;
-        cw[r] = p.cptr_w + (int64_t)hj * sw_cw_stride(n_win) + SW_CW_LEAD;                           // entry offsets of the row per window
-        base32[r] = has_row[r] ? (uint32_t)p.cptr[(int64_t)hj * (p.n_chunks + 1)] : 0u;             // the row's first entry (< 2^30 entries in all)
     }
-    struct Pre { uint2 ent[ROWS][SW_PRE]; int first[ROWS], end[ROWS], more[ROWS]; };
-    auto issue = [&](Pre &s, const int *qa, const int *qb) __attribute__((always_inline)) {
+    struct Pre { u32x4 w[ROWS]; };
+    // (unconditional loads at valid addresses: a lane without a row reads row 0 and ignores it)
+    auto issue = [&](Pre &s, int c) __attribute__((always_inline)) {
+        const int cc = min(c, n_win - 1);
 #pragma unroll
-        for (int r = 0; r < ROWS; ++r) {
-            const int last = max(qb[r] - 1, 0);
-            const uint2 *const src = rp + (base32[r] + (uint32_t)min(qa[r] + l * per, last));      // (reads past the segment / the array's end land in the pad)
-            const u32x4_a8 two = *reinterpret_cast<const u32x4_a8 *>(src);
-            s.ent[r][0] = make_uint2(two[0], two[1]);
-            s.ent[r][1] = make_uint2(two[2], two[3]);
-            if (three) s.ent[r][2] = src[2]; else s.ent[r][2] = make_uint2(0u, 0u);
-            s.first[r] = qa[r] + l * per;
-            s.end[r] = qb[r];
-            s.more[r] = qa[r] + per * L + l;              // this lane's first entry beyond the prefetch
-        }
+        for (int r = 0; r < ROWS; ++r) s.w[r] = mw[(uint32_t)hj[r] * (uint32_t)n_win + (uint32_t)cc];
     };
-    auto consume = [&](const Pre &s, int colA) __attribute__((always_inline)) {
+    auto count_of = [&](const Pre &s, int r) __attribute__((always_inline)) -> int { return has_row[r] ? (int)(s.w[r][3] >> 30) : 0; };
+    auto col_of = [&](const Pre &s, int r, int t) __attribute__((always_inline)) -> int { return (int)((s.w[r][3] >> (10 * t)) & 1023u); };
+    auto more_of = [&](const Pre &s, int r) __attribute__((always_inline)) -> bool {
+        return count_of(s, r) == 3 && col_of(s, r, 1) > col_of(s, r, 2);
+    };
+    // entries 3 ... of a marked segment: [q0, q1) in the pair array
+    auto rest_of = [&](int r, int c, uint32_t &q0, uint32_t &q1) __attribute__((always_inline)) {
+        const uint32_t *const cw = p.cptr_w + (int64_t)hj[r] * sw_cw_stride(n_win) + SW_CW_LEAD;
+        const uint32_t base = (uint32_t)p.cptr[(int64_t)hj[r] * (p.n_chunks + 1)];        // the row's first entry (< 2^30 entries in all)
+        q0 = base + cw[c] + 3u;
+        q1 = base + cw[c + 1];
+    };
+    auto consume = [&](const Pre &s, int c, int colA) __attribute__((always_inline)) {
+        bool more = false;
 #pragma unroll
         for (int r = 0; r < ROWS; ++r) {
+            const int n = count_of(s, r);
 #pragma unroll
-            for (int t = 0; t < SW_PRE; ++t) {
-                if (t == 2 && !three) break;
-                const bool ok = s.first[r] + t < s.end[r];
-                const double a = fma(x[r], (double)__uint_as_float(s.ent[r][t].y), SD_MAGIC) - SD_MAGIC;
-                atomicAdd(&S.tab[ok ? (int)s.ent[r][t].x - colA : SW_WIN + lane], ok ? a : 0.0);
+            for (int t = 0; t < 3; ++t) {
+                const bool ok = t < n;
+                const double a = fma(x[r], (double)__uint_as_float(s.w[r][t]), SD_MAGIC) - SD_MAGIC;
+                atomicAdd(&S.tab[ok ? col_of(s, r, t) : SW_WIN + lane], ok ? a : 0.0);
             }
+            more |= more_of(s, r);
         }
+        if (__builtin_expect(__any(more) != 0, 0)) {      // segments with more than three entries (rare on the matrices this kernel is picked for)
 #pragma unroll
-        for (int r = 0; r < ROWS; ++r)
-            for (int q = s.more[r]; q < s.end[r]; q += L) {            // segments longer than the prefetch (rare)
-                const uint2 e2 = rp[base32[r] + (uint32_t)q];
-                atomicAdd(&S.tab[(int)e2.x - colA], fma(x[r], (double)__uint_as_float(e2.y), SD_MAGIC) - SD_MAGIC);
-            }
+            for (int r = 0; r < ROWS; ++r)
+                if (more_of(s, r)) {
+                    uint32_t q0, q1;
+                    rest_of(r, c, q0, q1);
+                    for (uint32_t q = q0; q < q1; ++q) {
+                        const uint2 e2 = rp[q];
+                        atomicAdd(&S.tab[(int)e2.x - colA], fma(x[r], (double)__uint_as_float(e2.y), SD_MAGIC) - SD_MAGIC);
+                    }
+                }
+        }
     };
     Pre A, B;
-    int b1[ROWS];
-    typedef uint32_t u32x4_a8w __attribute__((ext_vector_type(4), aligned(8)));
-    u32x4_a8w onext[ROWS];                                // offsets of windows 2 ... 5: one 16-byte load per four windows and row
-    {
-        int zero[ROWS];
-#pragma unroll
-        for (int r = 0; r < ROWS; ++r) {
-            b1[r] = has_row[r] ? (int)cw[r][1] : 0;
-            onext[r] = *reinterpret_cast<const u32x4_a8w *>(cw[r] + 2);
-            zero[r] = 0;
-        }
-        issue(A, zero, b1);
-    }
-    // The common window -- the list is full and no claimed sum beats its K-th -- is kept to the loads, the adds, the
-    // exchanges and ONE vote; everything else (candidates, segments longer than the prefetch, the short list of the first
-    // window, merges) sits behind that vote.
+    issue(A, 0);
+    // The common window -- the list is full and no claimed sum beats its K-th -- is kept to the load, the adds, the
+    // exchanges and ONE vote; everything else (candidates, marked segments, the short list of the first window, merges)
+    // sits behind that vote.
     double tau_eff = -INFINITY;                           // the K-th sum while the list is full, else -inf (every sum is a candidate)
-    auto window = [&](int c, const Pre &cur, Pre &nxt, const u32x4_a8w *o, int oi) __attribute__((always_inline)) {
+    auto window = [&](int c, const Pre &cur, Pre &nxt) __attribute__((always_inline)) {
         const int colA = c * SW_WIN;
-        int b2[ROWS];
-#pragma unroll
-        for (int r = 0; r < ROWS; ++r) b2[r] = has_row[r] ? (int)o[r][oi] : 0;
-        issue(nxt, b1, b2);                               // window c + 1 (an empty range past the last window)
-        consume(cur, colA);
-#pragma unroll
-        for (int r = 0; r < ROWS; ++r) b1[r] = b2[r];
+        issue(nxt, c + 1);                                // (past the last window: the last one again, never used)
+        consume(cur, c, colA);
         // the window's sums are complete: the LDS performs one wave's operations in issue order, so the exchanges below
         // find every lane's adds without waiting for them (only the compiler must keep the order)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
-        double v[ROWS][SW_PRE];
+        double v[ROWS][3];
         bool look = false;
 #pragma unroll
         for (int r = 0; r < ROWS; ++r) {
+            const int n = count_of(cur, r);
 #pragma unroll
-            for (int t = 0; t < SW_PRE; ++t) {
-                if (t == 2 && !three) { v[r][t] = 0.0; break; }
-                const bool ok = cur.first[r] + t < cur.end[r];
-                v[r][t] = claim(ok ? (int)cur.ent[r][t].x - colA : SW_WIN + lane);
-            }
-            look |= cur.more[r] < cur.end[r];             // a segment longer than the prefetch
+            for (int t = 0; t < 3; ++t) v[r][t] = claim(t < n ? col_of(cur, r, t) : SW_WIN + lane);
+            look |= more_of(cur, r);
         }
 #pragma unroll
         for (int r = 0; r < ROWS; ++r)
 #pragma unroll
-            for (int t = 0; t < SW_PRE; ++t) look |= v[r][t] > tau_eff;
+            for (int t = 0; t < 3; ++t) look |= v[r][t] > tau_eff;
         if (__builtin_expect(__any(look) == 0, 1)) return;
         const bool full = cnt == K;
 #pragma unroll
-        for (int r = 0; r < ROWS; ++r)
-            for (int q = cur.more[r]; __any(q < cur.end[r]); q += L) {    // (wave-uniform trip count for the ballots)
-                const bool in = q < cur.end[r];
-                const int col = in ? (int)rp[base32[r] + (uint32_t)q].x : 0;
-                const double vv = in ? claim(col - colA) : 0.0;
-                append(in && vv != 0.0 && (!full || vv > tau), vv, col);
+        for (int r = 0; r < ROWS; ++r) {
+            const bool mr = more_of(cur, r);
+            if (__any(mr)) {
+                uint32_t q0 = 0, q1 = 0;
+                if (mr) rest_of(r, c, q0, q1);
+                for (uint32_t q = q0; __any(q < q1); ++q) {      // (wave-uniform trip count for the ballots)
+                    const bool in = q < q1;
+                    const int col = in ? (int)rp[q].x : 0;
+                    const double vv = in ? claim(col - colA) : 0.0;
+                    append(in && vv != 0.0 && (!full || vv > tau), vv, col);
+                }
             }
+        }
         if (full) {
 #pragma unroll
             for (int r = 0; r < ROWS; ++r)
 #pragma unroll
-                for (int t = 0; t < SW_PRE; ++t) append(v[r][t] != 0.0 && v[r][t] > tau, v[r][t], (int)cur.ent[r][t].x);   // (a zero passes the vote when the K-th sum is negative)
+                for (int t = 0; t < 3; ++t) append(v[r][t] != 0.0 && v[r][t] > tau, v[r][t], colA + col_of(cur, r, t));   // (a zero passes the vote when the K-th sum is negative)
         } else if ([&]() { bool nz = false;
 #pragma unroll
                            for (int r = 0; r < ROWS; ++r)
 #pragma unroll
-                               for (int t = 0; t < SW_PRE; ++t) nz |= v[r][t] != 0.0;
+                               for (int t = 0; t < 3; ++t) nz |= v[r][t] != 0.0;
                            return __any(nz) != 0; }()) {
             // short list: a lower bound of the window's K-th best sum by a bit-by-bit search over the order-preserving
             // high words of ALL claimed sums (ballot + popcount; excluded columns are looked up first)
-            uint32_t key[ROWS][SW_PRE];
+            uint32_t key[ROWS][3];
 #pragma unroll
             for (int r = 0; r < ROWS; ++r)
 #pragma unroll
-                for (int t = 0; t < SW_PRE; ++t) {
-                    if (v[r][t] != 0.0 && n_ex != 0 && excluded((int)cur.ent[r][t].x)) v[r][t] = 0.0;
+                for (int t = 0; t < 3; ++t) {
+                    if (v[r][t] != 0.0 && n_ex != 0 && excluded(colA + col_of(cur, r, t))) v[r][t] = 0.0;
                     const uint32_t hi = (uint32_t)__double2hiint(v[r][t]);
                     key[r][t] = v[r][t] != 0.0 ? (hi ^ ((uint32_t)((int32_t)hi >> 31) | 0x80000000u)) : 0u;
                 }
@@ -1289,31 +1278,29 @@ __global__ __launch_bounds__(64 * SW_WAVES) __attribute__((amdgpu_waves_per_eu(4
 #pragma unroll
                 for (int r = 0; r < ROWS; ++r)
 #pragma unroll
-                    for (int t = 0; t < SW_PRE; ++t) n_at += __popcll(__ballot(key[r][t] >= trial));
+                    for (int t = 0; t < 3; ++t) n_at += __popcll(__ballot(key[r][t] >= trial));
                 if (n_at >= K) fl = trial;
             }
             const uint32_t floor_k = max(fl, 1u);
 #pragma unroll
             for (int r = 0; r < ROWS; ++r)
 #pragma unroll
-                for (int t = 0; t < SW_PRE; ++t) append(key[r][t] >= floor_k, v[r][t], (int)cur.ent[r][t].x);
+                for (int t = 0; t < 3; ++t) append(key[r][t] >= floor_k, v[r][t], colA + col_of(cur, r, t));
         }
         if (!over && nq > cnt && (!full || nq - cnt >= SD_LAZY + K || nq + 24 > SW_CAND)) merge();   // lazy, like the kernel above
         tau_eff = cnt == K ? tau : -INFINITY;
     };
-    for (int c = 0; c < n_win && !over; c += 4) {
-        u32x4_a8w o[ROWS];                                // offsets of windows c + 2 ... c + 5 (requested four windows ago)
-#pragma unroll
-        for (int r = 0; r < ROWS; ++r) { o[r] = onext[r]; onext[r] = *reinterpret_cast<const u32x4_a8w *>(cw[r] + c + 6); }
-        window(c, A, B, o, 0);
-        if (c + 1 < n_win && !over) window(c + 1, B, A, o, 1);
-        if (c + 2 < n_win && !over) window(c + 2, A, B, o, 2);
-        if (c + 3 < n_win && !over) window(c + 3, B, A, o, 3);
+    for (int c = 0; c < n_win && !over; c += 2) {
+        window(c, A, B);
+        if (c + 1 < n_win && !over) window(c + 1, B, A);
     }
     };
-    if (m > 64) sweep(std::true_type{}, std::integral_constant<int, 2>{});
-    else if (L == 1) sweep(std::true_type{}, std::integral_constant<int, 1>{});
-    else sweep(std::false_type{}, std::integral_constant<int, 1>{});
+    if constexpr (SW_ROWS >= 4) {
+        if (m > 128) { sweep(std::integral_constant<int, 4>{}); goto swept; }
+    }
+    if (m > 64) sweep(std::integral_constant<int, 2>{});
+    else sweep(std::integral_constant<int, 1>{});
+swept:
     if (!over && nq > cnt) merge();
     // zero-sum columns (score 0 * col_scale) can still rank when the list is short or ends at or below zero: the sweep
     // over them lives in the workgroup kernel
@@ -1337,6 +1324,38 @@ __global__ void build_win_ptr_kernel(const int64_t *cptr, int nc1, const int32_t
     const int64_t target = (int64_t)c * SW_WIN;
     while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (idx[mid] < target) lo = mid + 1; else hi = mid; }
     cw[t] = (uint32_t)(lo - b);
+}
+
+// The window words of the wave-per-user kernel: per (row, window) one 16-byte word = the segment's first three entries
+// (fp32 values in words 0 ... 2; word 3 = three 10-bit columns inside the window + the count in the top two bits).  A
+// segment with more than three entries stores its second and third entry SWAPPED (columns descending: impossible
+// otherwise), which tells the kernel to fetch the rest from the pair array.
+__global__ void build_win_words_kernel(const uint32_t *cw, const int64_t *cptr, int nc1, const uint2 *pair, int64_t n_rows, int n_win, uint4 *out)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_rows * n_win) return;
+    const int64_t r = t / n_win;
+    const int c = (int)(t - r * n_win);
+    const uint32_t *row = cw + r * sw_cw_stride(n_win) + SW_CW_LEAD;
+    const uint32_t q0 = row[c], q1 = row[c + 1];
+    const int64_t base = cptr[r * nc1];
+    const int n = (int)(q1 - q0), cnt = n < 3 ? n : 3;
+    uint2 e[3] = {make_uint2(0u, 0u), make_uint2(0u, 0u), make_uint2(0u, 0u)};
+    for (int k = 0; k < cnt; ++k) {
+        e[k] = pair[base + q0 + k];
+        e[k].x -= (uint32_t)c * SW_WIN;
+    }
+    if (n > 3) { const uint2 x = e[1]; e[1] = e[2]; e[2] = x; }
+    out[t] = make_uint4(e[0].y, e[1].y, e[2].y, e[0].x | (e[1].x << 10) | (e[2].x << 20) | ((uint32_t)cnt << 30));
+}
+
+int launch_build_win_words(const uint32_t *cw, const int64_t *cptr, int n_chunks, const uint2 *pair, int64_t n_rows, int n_win, void *out, hipStream_t s)
+{
+    const int64_t total = n_rows * n_win;
+    if (total <= 0) return 0;
+    if (total >= ((int64_t)1 << 32)) return -1;
+    hipLaunchKernelGGL(build_win_words_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, cw, cptr, n_chunks + 1, pair, n_rows, n_win, (uint4 *)out);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
 // (row, window) segments with more entries than a lane prefetches: the wave-per-user kernel walks those one load at a
@@ -1395,7 +1414,7 @@ int launch_item_sparse_topk(const ItemItemParams &p, int32_t *out_ids, float *ou
     const int cap = p.sp_cap == 0 ? SD_CAND : (p.sp_cap < p.K ? p.K : (p.sp_cap > SD_CAND ? SD_CAND : p.sp_cap));
     // fewer than 2^30 entries (+ the over-read pad): 32-bit entry indices from the array bases (fewer address instructions)
     const bool idx32 = p.m_nnz + II_CSR_PAD < ((int64_t)1 << 30);
-    if (p.cptr_w != nullptr && p.long_list != nullptr && idx32 && p.K <= SW_MAXK) {
+    if (p.cptr_w != nullptr && p.m_win != nullptr && p.long_list != nullptr && idx32 && p.K <= SW_MAXK) {
         // one wave per user; what that kernel hands over (long histories, lists that zero-sum columns may enter, mass
         // ties) is ranked by the workgroup kernel in list mode -- a fixed-size grid that reads the count on the device
         if (hipMemsetAsync(p.long_cnt, 0, sizeof(int), stream) != hipSuccess) return -3;
