@@ -1027,7 +1027,7 @@ __global__ __launch_bounds__(SD_BLOCK, 4) void item_sparse_topk_kernel(ItemItemP
 constexpr int SW_WIN = 1024;                            // columns per window
 constexpr int SW_PRE = 3;                               // entries per lane prefetched one window ahead
 constexpr int SW_CAND = 96;                             // the list + pending candidates
-constexpr int SW_ROWS = 3;                              // history rows per lane, at most (histories of up to 192 rows)
+constexpr int SW_ROWS = 4;                              // history rows per lane, at most (histories of up to 256 rows)
 constexpr int SW_MAXK = 32;                             // longest list of this kernel (longer ones: the workgroup kernel)
 constexpr int SW_EXL = 32;                              // exclusion row entries kept in LDS
 constexpr int SW_WAVES = 1;                             // users (waves) per workgroup
@@ -1295,7 +1295,8 @@ __global__ __launch_bounds__(64 * SW_WAVES) __attribute__((amdgpu_waves_per_eu(4
         if (c + 1 < n_win && !over) window(c + 1, B, A);
     }
     };
-    if (m > 128) sweep(std::integral_constant<int, SW_ROWS>{});
+    if (m > 192) sweep(std::integral_constant<int, 4>{});
+    else if (m > 128) sweep(std::integral_constant<int, 3>{});
     else if (m > 64) sweep(std::integral_constant<int, 2>{});
     else sweep(std::integral_constant<int, 1>{});
     if (!over && nq > cnt) merge();
