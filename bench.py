@@ -359,7 +359,7 @@ def run_config(config, args, steps, warmup, world, rank, dev, D, with_cpu, var):
         if not dense:
             # the HBM roof is the contract's statement for this byte-moving path; what limits the kernel is instruction
             # issue (constants of the committed counter run, like `traffic`)
-            roof["limiter"] = "no single pipe: a dependent LDS / barrier chain per 4096-column window, see profiles/r03_c5_sq_counters.json"
+            roof["limiter"] = "instruction issue of the wave-per-user kernel (VALU about 75 % of SIMD cycles), not the memory path: see profiles/r03_c5_sq_counters.json"
         cfg = {"workload": workload, "users_per_gpu": n, "items": w["n_items"], "topk": TOPK,
                "parallelism": f"users sharded x{world}, item matrix replicated"}
     else:

@@ -59,8 +59,9 @@ const char *ifr_last_error(ifr_handle h);
  * "wide_chunk_cap", "wide_stats": tuning / statistics of that path; "item_f64": see ifr_fit_ease (none of these
  * changes a result);
  * "csr_wave": CSR top-K kernel choice -- 0 = the workgroup-per-user kernel only; 1 (default) = one wave per user where
- * the history has at most 128 rows (the rest handed to the workgroup kernel), IF at most 1 % of the matrix's (row,
- * 1024-column window) segments hold more than the three entries that kernel prefetches (measured when the matrix is
+ * the history has at most 256 rows (the rest handed to the workgroup kernel; needs the kernel's side table of one
+ * 16-byte word per matrix row and 1024-column window, built when it stays within twice the entries' bytes / 256 MB), IF at most 0.3 % of the matrix's (row,
+ * 1024-column window) segments hold more than the three entries a word of that table holds (measured when the matrix is
  * set: evenly spread rows; on matrices with uniformly drawn columns the workgroup kernel is the faster one); 2 = force
  * the wave kernel (tests).  Same results either way;
  * "csr_cand_cap": entries of the CSR top-K kernel's buffer of candidates that wait to be merged into a user's list
@@ -201,7 +202,7 @@ int ifr_read_eval_csr(ifr_handle h, int which, int64_t *indptr, int32_t *indices
  * ascending on ties.  out_ids/out_scores: dev [n][K]; unfilled slots (fewer than K
  * candidates) hold id -1 / score -inf.  user_ids: dev [n].
  * 1 <= K <= IFR_MAX_TOPK for dot-product models, IFR_MAX_TOPK_ITEM for dense item matrices, IFR_MAX_TOPK_ITEM_CSR for
- * CSR item matrices (K <= 32: histories of at most 128 rows by the wave-per-user kernel where the matrix suits it, see
+ * CSR item matrices (K <= 32: histories of at most 256 rows by the wave-per-user kernel where the matrix suits it, see
  * "csr_wave"; everything else by the workgroup-per-user kernel).  Dot-product models, K <= 16: lane-private
  * sorted lists, merged per user; the call is asynchronous on `stream`.  16 < K <= 100 (dot-product models): the same
  * kernel; a user's two 16-entry lists per item chunk (2 ... 8 chunks, about K / 12) hold the top K unless more than

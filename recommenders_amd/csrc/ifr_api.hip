@@ -807,10 +807,12 @@ int ifr_set_item_matrix_csr(ifr_handle h, const int64_t *indptr, const int32_t *
                 hipMalloc((void **)&h->ii_cptr_w, wbytes) == hipSuccess) {
                 h->ii_n_win = n_win;
                 lrc = ifr::launch_build_win_ptr(h->ii_cptr, n_chunks, h->ii_idx, n_items, n_win, h->ii_cptr_w, 0);
-                // The wave-per-user kernel prefetches three entries per row and window and walks longer segments one load
-                // at a time: it only pays on matrices whose rows spread evenly over the windows (C5's synthetic W; with
-                // uniformly drawn columns 16 % of the segments are longer and it loses to the workgroup kernel).  More
-                // than 1 % long segments: the workgroup kernel serves every user (unless option csr_wave = 2 forces it).
+                // The wave-per-user kernel reads three entries per row and window (one 16-byte word) and fetches the rest
+                // of a longer segment through two dependent loads: it only pays on matrices whose rows spread evenly over
+                // the windows (C5's synthetic W; with uniformly drawn columns 16 % of the segments are longer and it runs
+                // at half the workgroup kernel's rate).  A wave holds ~25 rows, so with a share f of long segments about
+                // 25 f of its windows take that path at ~5 x a window's time: break-even near f = 1 %.  More than 0.3 %
+                // long segments: the workgroup kernel serves every user (unless option csr_wave = 2 forces it).
                 unsigned long long *d_long = nullptr, n_long = 0;
                 if (!lrc && (hipMalloc((void **)&d_long, sizeof(n_long)) != hipSuccess || hipMemset(d_long, 0, sizeof(n_long)) != hipSuccess)) lrc = -4;
                 if (!lrc) lrc = ifr::launch_count_long_segments(h->ii_cptr_w, n_items, n_win, d_long, 0);
@@ -991,7 +993,7 @@ static int rank_topk_item_item(ifr_handle h, const int32_t *user_ids, int64_t n,
     p.K = K; p.KL = KL;
     std::pair<hipEvent_t, hipEvent_t> ev;
     if (h->mode == MODE_ITEM_CSR) {                  // one workgroup per user, final lists written directly
-        if (h->ii_cptr_w != nullptr && h->ii_win != nullptr && (h->opt_csr_wave == 2 || (h->opt_csr_wave == 1 && h->ii_long_frac <= 0.01))) {
+        if (h->ii_cptr_w != nullptr && h->ii_win != nullptr && (h->opt_csr_wave == 2 || (h->opt_csr_wave == 1 && h->ii_long_frac <= 0.003))) {
             rc = grow(h, &h->ws_long, &h->ws_long_bytes, sizeof(int32_t) * ((size_t)n + 1));
             if (rc) return rc;
             p.cptr_w = h->ii_cptr_w; p.n_win = h->ii_n_win; p.m_win = h->ii_win;

@@ -1014,13 +1014,13 @@ __global__ __launch_bounds__(SD_BLOCK, 4) void item_sparse_topk_kernel(ItemItemP
 // The same sweep with ONE WAVE per user (round 3, last step): the workgroup-per-user kernel above spends its time in a
 // dependent chain per window -- adds, LDS drain, barrier, exchanges, barrier, counter read -- that only the four
 // workgroups a CU holds can overlap, and all four waves of a workgroup execute the same scalar bookkeeping.  A user
-// with at most 128 history rows needs neither: a wave keeps a row (65 ... 128 rows: two) per lane, a private table of
-// 1 024 direct-mapped fp64 accumulators (8 KB) and its candidate buffer; nothing crosses waves, so there is no s_barrier
+// with at most 256 history rows needs neither: a wave keeps a row (longer histories: two, three or four) per lane, a
+// private table of 1 024 direct-mapped fp64 accumulators (8 KB) and its candidate buffer; nothing crosses waves, so there is no s_barrier
 // and no shared counter -- candidate slots come from a ballot prefix -- and a CU holds 16 independent users, each a
 // workgroup of its own (with four users per workgroup the LDS of three finished waves waited for the slowest: K = 32
 // 17 % slower).  Arithmetic, exchange-claim selection, lazy merges and the exact-domain ranking are those of the kernel
 // above (same results bit for bit).
-// What this kernel does not serve it hands to the workgroup kernel through p.long_list: histories beyond 128 rows,
+// What this kernel does not serve it hands to the workgroup kernel through p.long_list: histories beyond 256 rows,
 // users whose list ends short or with a K-th sum <= 0 (zero-sum columns may rank: the sweep over them lives there),
 // and a candidate buffer that overflows (mass ties).
 // ------------------------------------------------------------------------------------

@@ -93,7 +93,7 @@ def test_c5_shape_csr_125000_items_256_neighbours_bit_exact(torch, cand_cap, wav
     sc.set_history_csr(h_ptr, h_idx, h_val)
     sc.set_exclusion_csr(h_ptr, h_idx)
     sc.set_truth_csr(t_ptr, t_idx)
-    sc.set_option("csr_wave", wave)             # 1 / 2: one wave per user (histories <= 128 rows; 2 = whatever the matrix looks like), the rest handed over
+    sc.set_option("csr_wave", wave)             # 1 / 2: one wave per user (histories <= 256 rows; 2 = whatever the matrix looks like), the rest handed over
     if cand_cap:
         sc.set_option("csr_cand_cap", cand_cap)
     users = np.r_[np.arange(len(lengths)), [len(lengths) + 9]].astype(np.int32)

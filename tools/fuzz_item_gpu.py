@@ -17,7 +17,7 @@ for case in range(cases):
     K = int(rng.choice([1, 5, 10, 20, 32]))
     if form == "csr" and rng.integers(2):
         K = int(rng.choice([33, 50, 64, 65, 100, 128]))
-    mean_hist = float(rng.choice([0.5, 5, 40, 90, 300]))
+    mean_hist = float(rng.choice([0.5, 5, 40, 90, 150, 220, 300]))
     pen = bool(rng.integers(2))
     neg = bool(rng.integers(2))
     lens = np.minimum(rng.poisson(mean_hist, n_users), n_items)
