@@ -1088,12 +1088,12 @@ __global__ __launch_bounds__(64 * SW_WAVES) __attribute__((amdgpu_waves_per_eu(4
 
     // A lane keeps ONE history row for the whole sweep -- or two / four rows (lane, lane + 64, ...: histories of up to 256
     // rows).  The row's entries come from the WINDOW WORDS (m_win, built at set time): one 16-byte word per (row, window)
-    // that packs up to three entries -- three fp32 values + 3 x 10 bits of column inside the window + a 2-bit count --
+    // that packs up to three entries -- three fp32 values + 3 x 10 bits of column inside the window + a flag --
     // so a window costs a lane ONE load at an address that is a plain stride (no entry offsets to fetch first).  What a
     // wave's load costs here is the cache-line look-up per lane, not the bytes: 8-byte entries took three loads + an
     // offset load per window, then a 16-byte + an 8-byte load + a quarter of an offset load (20.7 -> 24.4 M users/s at
-    // C5), now one.  A segment with more than three entries is marked in its word (count 3 with the second and third
-    // column swapped -- their order does not matter to a sum) and its other entries are read from the pair array.
+    // C5), now one.  A segment with more than three entries is flagged in its word and its other entries are read from
+    // the pair array.
     const uint2 *const rp = p.m_pair;
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     const u32x4 *const mw = reinterpret_cast<const u32x4 *>(p.m_win);
@@ -1166,11 +1166,15 @@ __global__ __launch_bounds__(64 * SW_WAVES) __attribute__((amdgpu_waves_per_eu(4
 #pragma unroll
         for (int r = 0; r < ROWS; ++r) s.w[r] = mw[(uint32_t)hj[r] * (uint32_t)n_win + (uint32_t)cc];
     };
-    auto count_of = [&](const Pre &s, int r) __attribute__((always_inline)) -> int { return has_row[r] ? (int)(s.w[r][3] >> 30) : 0; };
+    // A word always holds three (column, value) pairs: where the segment has fewer entries the spare pairs carry the
+    // value 0 and the column of a real pair (or column 0).  Adding 0 changes nothing, and the exchange that follows
+    // may well return the slot's sum to this lane instead of the lane whose entry it is -- whoever claims a slot reports
+    // its column, which the slot number gives.  So the common window has no counts and no per-entry masks.
     auto col_of = [&](const Pre &s, int r, int t) __attribute__((always_inline)) -> int { return (int)((s.w[r][3] >> (10 * t)) & 1023u); };
-    auto more_of = [&](const Pre &s, int r) __attribute__((always_inline)) -> bool {
-        return count_of(s, r) == 3 && col_of(s, r, 1) > col_of(s, r, 2);
-    };
+    // (a lane without a row keeps to a slot of its own behind the table: forty lanes adding zeros to row 0's slots would
+    // queue up at the same LDS address)
+    auto slot_of = [&](const Pre &s, int r, int t) __attribute__((always_inline)) -> int { return has_row[r] ? col_of(s, r, t) : SW_WIN + lane; };
+    auto more_of = [&](const Pre &s, int r) __attribute__((always_inline)) -> bool { return has_row[r] && (s.w[r][3] >> 30) != 0u; };
     // entries 3 ... of a marked segment: [q0, q1) in the pair array
     auto rest_of = [&](int r, int c, uint32_t &q0, uint32_t &q1) __attribute__((always_inline)) {
         const uint32_t *const cw = p.cptr_w + (int64_t)hj[r] * sw_cw_stride(n_win) + SW_CW_LEAD;
@@ -1182,13 +1186,9 @@ __global__ __launch_bounds__(64 * SW_WAVES) __attribute__((amdgpu_waves_per_eu(4
         bool more = false;
 #pragma unroll
         for (int r = 0; r < ROWS; ++r) {
-            const int n = count_of(s, r);
 #pragma unroll
-            for (int t = 0; t < 3; ++t) {
-                const bool ok = t < n;
-                const double a = fma(x[r], (double)__uint_as_float(s.w[r][t]), SD_MAGIC) - SD_MAGIC;
-                atomicAdd(&S.tab[ok ? col_of(s, r, t) : SW_WIN + lane], ok ? a : 0.0);
-            }
+            for (int t = 0; t < 3; ++t)
+                atomicAdd(&S.tab[slot_of(s, r, t)], fma(x[r], (double)__uint_as_float(s.w[r][t]), SD_MAGIC) - SD_MAGIC);
             more |= more_of(s, r);
         }
         if (__builtin_expect(__any(more) != 0, 0)) {      // segments with more than three entries (rare on the matrices this kernel is picked for)
@@ -1223,16 +1223,16 @@ __global__ __launch_bounds__(64 * SW_WAVES) __attribute__((amdgpu_waves_per_eu(4
         bool look = false;
 #pragma unroll
         for (int r = 0; r < ROWS; ++r) {
-            const int n = count_of(cur, r);
 #pragma unroll
-            for (int t = 0; t < 3; ++t) v[r][t] = claim(t < n ? col_of(cur, r, t) : SW_WIN + lane);
+            for (int t = 0; t < 3; ++t) v[r][t] = claim(slot_of(cur, r, t));
             look |= more_of(cur, r);
         }
+        unsigned long long any = __ballot(look);          // (compares, not a maximum tree: fmax canonicalises its operands, an instruction each)
 #pragma unroll
         for (int r = 0; r < ROWS; ++r)
 #pragma unroll
-            for (int t = 0; t < 3; ++t) look |= v[r][t] > tau_eff;
-        if (__builtin_expect(__any(look) == 0, 1)) return;
+            for (int t = 0; t < 3; ++t) any |= __ballot(v[r][t] > tau_eff);
+        if (__builtin_expect(any == 0ull, 1)) return;
         const bool full = cnt == K;
 #pragma unroll
         for (int r = 0; r < ROWS; ++r) {
@@ -1325,9 +1325,10 @@ __global__ void build_win_ptr_kernel(const int64_t *cptr, int nc1, const int32_t
 }
 
 // The window words of the wave-per-user kernel: per (row, window) one 16-byte word = the segment's first three entries
-// (fp32 values in words 0 ... 2; word 3 = three 10-bit columns inside the window + the count in the top two bits).  A
-// segment with more than three entries stores its second and third entry SWAPPED (columns descending: impossible
-// otherwise), which tells the kernel to fetch the rest from the pair array.
+// (fp32 values in words 0 ... 2; word 3 = three 10-bit columns inside the window; bit 30 = the segment has more entries:
+// the kernel fetches the rest from the pair array).  A segment with fewer than three entries fills the spare pairs with
+// the value 0 and the column of its first entry (an empty one: a column that depends on the row): the kernel treats all
+// three alike.
 __global__ void build_win_words_kernel(const uint32_t *cw, const int64_t *cptr, int nc1, const uint2 *pair, int64_t n_rows, int n_win, uint4 *out)
 {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1343,8 +1344,9 @@ __global__ void build_win_words_kernel(const uint32_t *cw, const int64_t *cptr, 
         e[k] = pair[base + q0 + k];
         e[k].x -= (uint32_t)c * SW_WIN;
     }
-    if (n > 3) { const uint2 x = e[1]; e[1] = e[2]; e[2] = x; }
-    out[t] = make_uint4(e[0].y, e[1].y, e[2].y, e[0].x | (e[1].x << 10) | (e[2].x << 20) | ((uint32_t)cnt << 30));
+    if (cnt == 0) e[0].x = (uint32_t)(r & (SW_WIN - 1));              // (an empty segment: some column of the window, not the same one for every row)
+    for (int k = cnt; k < 3; ++k) e[k] = make_uint2(e[0].x, 0u);      // (value +0.0f)
+    out[t] = make_uint4(e[0].y, e[1].y, e[2].y, e[0].x | (e[1].x << 10) | (e[2].x << 20) | (n > 3 ? 1u << 30 : 0u));
 }
 
 int launch_build_win_words(const uint32_t *cw, const int64_t *cptr, int n_chunks, const uint2 *pair, int64_t n_rows, int n_win, void *out, hipStream_t s)
