@@ -1026,7 +1026,7 @@ __global__ __launch_bounds__(SD_BLOCK, 4) void item_sparse_topk_kernel(ItemItemP
 // ------------------------------------------------------------------------------------
 constexpr int SW_WIN = 1024;                            // columns per window
 constexpr int SW_PRE = 3;                               // entries per lane prefetched one window ahead
-constexpr int SW_CAND = 96;                             // the list + pending candidates
+constexpr int SW_CAND = 112;                            // the list + pending candidates
 constexpr int SW_ROWS = 4;                              // history rows per lane, at most (histories of up to 256 rows)
 constexpr int SW_MAXK = 32;                             // longest list of this kernel (longer ones: the workgroup kernel)
 constexpr int SW_EXL = 32;                              // exclusion row entries kept in LDS
