@@ -15,6 +15,8 @@ namespace ifr {
 constexpr int AUC_BLOCK = 256;
 constexpr int AUC_MAX_POS = 8192;
 constexpr int AUC_MAX_POS_F64 = 4096;          // the sorted positives' scores live in LDS: 32 KB of doubles
+constexpr int AUC_BUCKETS = 2048;              // score buckets of the per-user look-up table (8 KB of LDS)
+constexpr int AUC_LUT_MIN_POS = 5;             // fewer positives: the binary search is two or three steps anyway
 
 // four consecutive scores of a row, read as 16-byte words
 template <typename S> struct Vec4 { S x, y, z, w; };
@@ -101,10 +103,78 @@ __global__ __launch_bounds__(AUC_BLOCK) void auc_kernel(const S *scores, int64_t
         }
     }
     long long wins = 0;
-    // all items: four interleaved branch-free searches per thread (fixed log2(np2) + 1 LDS reads each, so
-    // the reads of the four chains overlap) over one 16-byte load of the score row
     int it0 = 0;
-    if ((ld & 3) == 0 && (reinterpret_cast<uintptr_t>(scores) & 15) == 0) {
+    // ---- all items, by a per-user look-up table over score BUCKETS (the common case).  The positives' scores span
+    // [lo, hi]; bucket(s) = min(fma(s, scale, off), BUCKETS - 1) converted to an unsigned integer is a monotone
+    // non-decreasing function of s (one fma, one min, one conversion: the same instructions for positives and items), so
+    //     #{p: s_p > s} = #{p: bucket(s_p) > bucket(s)} + #{p in the bucket of s: s_p > s}
+    // exactly.  The table holds the first count and the number of positives per bucket; the second term is a scan of
+    // the (almost always empty, rarely one-element) bucket in the sorted array.  A score below lo lands in bucket 0, one
+    // above hi in the last one, NaN in the last one (min returns the other operand; every compare is false: no win, as
+    // before).  Per score: ~9 VALU and one LDS read instead of a 6 - 7 step binary search of dependent LDS reads.
+    __shared__ uint32_t lut[AUC_BUCKETS];                          // low 16 bits: positives in higher buckets; high 16: positives in this one
+    __shared__ int scan_tot[AUC_BLOCK / 64];
+    const float lo_f = (float)ps[0], hi_f = (float)ps[n_pos - 1];
+    const bool use_lut = n_pos >= AUC_LUT_MIN_POS && n_pos < 65536 && (ld & 3) == 0 && (reinterpret_cast<uintptr_t>(scores) & 15) == 0 &&
+                         lo_f - lo_f == 0.0f && hi_f - hi_f == 0.0f;      // (finite ends; fp32 buckets also for fp64 scores: monotone all the same)
+    if (use_lut) {
+        float scale = hi_f > lo_f ? (float)(AUC_BUCKETS - 1) / (hi_f - lo_f) : 0.0f;
+        if (!(scale - scale == 0.0f)) scale = 0.0f;
+        const float off = -lo_f * scale;
+        auto bucket = [&](S v) __attribute__((always_inline)) -> uint32_t {
+            return (uint32_t)fminf(fmaf((float)v, scale, off), (float)(AUC_BUCKETS - 1));       // (negative -> 0, NaN -> last)
+        };
+        constexpr int PER = AUC_BUCKETS / AUC_BLOCK;               // consecutive buckets per thread
+        for (int q = threadIdx.x; q < AUC_BUCKETS; q += AUC_BLOCK) lut[q] = 0u;
+        __syncthreads();
+        for (int q = threadIdx.x; q < n_pos; q += AUC_BLOCK) atomicAdd(&lut[bucket(ps[q])], 1u << 16);
+        __syncthreads();
+        // suffix counts: thread t owns buckets [t PER, (t + 1) PER)
+        int mine = 0;
+        for (int k = 0; k < PER; ++k) mine += (int)(lut[threadIdx.x * PER + k] >> 16);
+        // positives in the buckets of higher threads: a suffix sum over the block (shuffles inside a wave, the four wave
+        // totals through LDS)
+        int suffix = mine;                                         // inclusive, within the wave
+        const int ln = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { const int o = __shfl_down(suffix, off); if (ln + off < 64) suffix += o; }
+        if (ln == 0) scan_tot[wv] = suffix;
+        __syncthreads();
+        int above = suffix - mine;
+        for (int w2 = wv + 1; w2 < AUC_BLOCK / 64; ++w2) above += scan_tot[w2];
+        for (int k = PER - 1; k >= 0; --k) {
+            const uint32_t e = lut[threadIdx.x * PER + k];
+            lut[threadIdx.x * PER + k] = (e & 0xffff0000u) | (uint32_t)above;
+            above += (int)(e >> 16);
+        }
+        __syncthreads();
+        const int n4 = n_items & ~3;
+        constexpr int STRIDE = 4 * AUC_BLOCK;
+        const Vec4<S> zero4 = {(S)0, (S)0, (S)0, (S)0};
+        Vec4<S> s_a = 4 * (int)threadIdx.x < n4 ? load4(row + 4 * threadIdx.x) : zero4;
+        Vec4<S> s_b = 4 * (int)threadIdx.x + STRIDE < n4 ? load4(row + 4 * threadIdx.x + STRIDE) : zero4;
+        unsigned int w32 = 0;
+        // the bucket's positives in the sorted array (almost always none, rarely one)
+        auto in_bucket = [&](S v, uint32_t e) __attribute__((always_inline)) {
+            const int n_in = (int)(e >> 16), first = n_pos - (int)(e & 0xffffu) - n_in;
+            for (int k = 0; k < n_in; ++k) w32 += ps[first + k] > v ? 1u : 0u;
+        };
+        for (int it = 4 * threadIdx.x; it < n4; it += STRIDE) {
+            const Vec4<S> s = s_a;
+            s_a = s_b;
+            if (it + 2 * STRIDE < n4) s_b = load4(row + it + 2 * STRIDE);
+            const uint32_t e0 = lut[bucket(s.x)], e1 = lut[bucket(s.y)], e2 = lut[bucket(s.z)], e3 = lut[bucket(s.w)];      // four reads in flight
+            w32 += (e0 & 0xffffu) + (e1 & 0xffffu) + (e2 & 0xffffu) + (e3 & 0xffffu);
+            if (__builtin_expect(__any(((e0 | e1 | e2 | e3) >> 16) != 0u) != 0, 0)) {
+                in_bucket(s.x, e0); in_bucket(s.y, e1); in_bucket(s.z, e2); in_bucket(s.w, e3);
+            }
+        }
+        wins += (long long)w32;                                    // (< 2^32: at most n_items / 256 * 65535 per thread)
+        it0 = n4;
+    }
+    // all items (few positives / unaligned rows): four interleaved branch-free searches per thread (fixed log2(np2) + 1 LDS reads each, so
+    // the reads of the four chains overlap) over one 16-byte load of the score row
+    if (!use_lut && (ld & 3) == 0 && (reinterpret_cast<uintptr_t>(scores) & 15) == 0) {
         const int n4 = n_items & ~3;
         // the row is read two iterations ahead: the searches below are chains of dependent LDS reads, and a load issued
         // at the top of its own iteration would add a trip to memory to every one of them
