@@ -59,11 +59,13 @@ const char *ifr_last_error(ifr_handle h);
  * "wide_chunk_cap", "wide_stats": tuning / statistics of that path; "item_f64": see ifr_fit_ease (none of these
  * changes a result);
  * "csr_wave": CSR top-K kernel choice -- 0 = the workgroup-per-user kernel only; 1 (default) = one wave per user where
- * the history has at most 256 rows (the rest handed to the workgroup kernel; needs the kernel's side table of one
- * 16-byte word per matrix row and 1024-column window, built when it stays within twice the entries' bytes / 256 MB), IF at most 0.3 % of the matrix's (row,
- * 1024-column window) segments hold more than the three entries a word of that table holds (measured when the matrix is
- * set: evenly spread rows; on matrices with uniformly drawn columns the workgroup kernel is the faster one); 2 = force
- * the wave kernel (tests).  Same results either way;
+ * the history has at most 256 rows (192 / 128 rows with two / three words per segment; the rest handed to the workgroup
+ * kernel; needs the kernel's side table of one to three 16-byte words -- three entries each -- per matrix row and
+ * 1024-column window, built when it stays within twice the entries' bytes / 256 MB), IF at most 0.3 % of the matrix's
+ * (row, 1024-column window) segments hold more entries than those words (the word count is chosen and the share
+ * measured when the matrix is set, ifr_item_csr_layout: evenly spread rows of up to ~1000 entries per 125 000 columns;
+ * on matrices with uniformly drawn columns the workgroup kernel is the faster one); 2 = force the wave kernel (tests).
+ * Same results either way;
  * "csr_cand_cap": entries of the CSR top-K kernel's buffer of candidates that wait to be merged into a user's list
  * (K ... 256, 0 = default 256; a value outside is clamped; tests shrink it to force the overflow path; no result changes);
  * "debug_mode": development ablations (results may change; the fused kernel's modes, bits 0-2
@@ -155,6 +157,12 @@ int ifr_fit_rp3beta(ifr_handle h, const int64_t *a_indptr, const int32_t *a_indi
  * max|M| and the largest history L1 norm so that no sum can overflow; lets a CPU checker
  * reproduce the scores bit-for-bit (no reference counterpart).  Needs matrix and histories set. */
 int ifr_item_fixed_point_shift(ifr_handle h, int *shift);
+
+/* How a CSR item matrix was laid out for the wave-per-user top-K kernel (see "csr_wave"; no reference counterpart):
+ * win_words = 16-byte words per matrix row and 1024-column window (1, 2 or 3: three entries each; 0 = that table was
+ * not built), long_share = the share of (row, window) segments that hold more entries than those words (the kernel is
+ * taken by default where it is at most 0.3 %).  Either pointer may be NULL. */
+int ifr_item_csr_layout(ifr_handle h, int *win_words, double *long_share);
 
 /* Per-user exclusion lists = items that must not be ranked: (train U validation positives)
  * minus test positives, already filtered by rating_threshold and clipped to [0, n_items)

@@ -48,6 +48,7 @@ SIGNATURES = {
     "ifr_set_item_matrix_csr": (ctypes.c_int, [vp, vp, vp, vp, ctypes.c_int64, ctypes.c_int64, vp]),
     "ifr_set_history_csr": (ctypes.c_int, [vp, vp, vp, vp, ctypes.c_int64, ctypes.c_int64]),
     "ifr_item_fixed_point_shift": (ctypes.c_int, [vp, ctypes.POINTER(ctypes.c_int)]),
+    "ifr_item_csr_layout": (ctypes.c_int, [vp, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_double)]),
     "ifr_set_exclusion_csr": (ctypes.c_int, [vp, vp, vp, ctypes.c_int64, ctypes.c_int64]),
     "ifr_set_truth_csr": (ctypes.c_int, [vp, vp, vp, ctypes.c_int64, ctypes.c_int64]),
     "ifr_build_eval_csrs": (ctypes.c_int, [vp, ctypes.POINTER(CsrSplit), ctypes.POINTER(CsrSplit), ctypes.POINTER(CsrSplit),

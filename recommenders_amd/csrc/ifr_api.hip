@@ -83,7 +83,7 @@ struct ifr_handle_s {
     int64_t *ii_cptr = nullptr; int32_t *ii_idx = nullptr; float *ii_val = nullptr; int64_t ii_nnz = 0;
     uint2 *ii_pair = nullptr;    // CSR entries as interleaved (column, value) pairs: what the CSR top-K kernel streams
     double ii_long_frac = 0.0;   // share of (row, 1024-column window) segments longer than that kernel's prefetch
-    void *ii_win = nullptr;                            // 16-byte window words of the wave-per-user kernel, or null
+    void *ii_win = nullptr; int ii_win_words = 1;      // 16-byte window words of the wave-per-user kernel (1 - 3 per row and window), or null
     uint32_t *ii_cptr_w = nullptr; int ii_n_win = 0;   // entry offsets per 1024-column window (wave-per-user CSR top-K kernel), or null
     void *ws_long = nullptr; size_t ws_long_bytes = 0;  // users that kernel hands over: [0] = count, then the list
     int opt_csr_wave = 1;        // 0: CSR top-K by the workgroup-per-user kernel only
@@ -813,19 +813,26 @@ int ifr_set_item_matrix_csr(ifr_handle h, const int64_t *indptr, const int32_t *
                 // at half the workgroup kernel's rate).  A wave holds ~25 rows, so with a share f of long segments about
                 // 25 f of its windows take that path at ~5 x a window's time: break-even near f = 1 %.  More than 0.3 %
                 // long segments: the workgroup kernel serves every user (unless option csr_wave = 2 forces it).
-                unsigned long long *d_long = nullptr, n_long = 0;
+                // A segment may take one, two or three words (3, 6, 9 entries; a lane then keeps 4, 2, 1 history rows): the
+                // fewest for which at most 0.3 % of the segments are longer still -- else one word, and the dispatch
+                // leaves the matrix to the workgroup kernel.
+                unsigned long long *d_long = nullptr, n_long[3] = {0, 0, 0};
                 if (!lrc && (hipMalloc((void **)&d_long, sizeof(n_long)) != hipSuccess || hipMemset(d_long, 0, sizeof(n_long)) != hipSuccess)) lrc = -4;
                 if (!lrc) lrc = ifr::launch_count_long_segments(h->ii_cptr_w, n_items, n_win, d_long, 0);
-                if (!lrc && hipMemcpy(&n_long, d_long, sizeof(n_long), hipMemcpyDeviceToHost) != hipSuccess) lrc = -3;
+                if (!lrc && hipMemcpy(n_long, d_long, sizeof(n_long), hipMemcpyDeviceToHost) != hipSuccess) lrc = -3;
                 dfree(d_long);
-                h->ii_long_frac = (double)n_long / std::max<double>(1.0, (double)n_items * n_win);
-                // the window words that kernel reads (one 16-byte word per row and window): where they stay within twice
-                // the entries' own bytes (or 256 MB) and 4 GB
-                const size_t win_bytes = (size_t)16 * (size_t)n_items * (size_t)n_win;
+                const double n_seg = std::max<double>(1.0, (double)n_items * n_win);
+                int words = 1;
+                while (words < 3 && (double)n_long[words - 1] / n_seg > 0.003) ++words;
+                if ((double)n_long[words - 1] / n_seg > 0.003) words = 1;
+                h->ii_win_words = words;
+                h->ii_long_frac = (double)n_long[words - 1] / n_seg;
+                // the window words that kernel reads: where they stay within twice the entries' own bytes (or 256 MB) and 4 GB
+                const size_t win_bytes = (size_t)16 * (size_t)n_items * (size_t)n_win * (size_t)words;
                 const size_t pair_bytes = sizeof(uint2) * (size_t)(nnz + ifr::item_csr_pad());
                 if (!lrc && win_bytes <= std::max<size_t>((size_t)256 << 20, 2 * pair_bytes) && win_bytes <= ((size_t)4 << 30) &&
                     hipMalloc(&h->ii_win, win_bytes) == hipSuccess)
-                    lrc = ifr::launch_build_win_words(h->ii_cptr_w, h->ii_cptr, n_chunks, (const uint2 *)h->ii_pair, n_items, n_win, h->ii_win, 0);
+                    lrc = ifr::launch_build_win_words(h->ii_cptr_w, h->ii_cptr, n_chunks, (const uint2 *)h->ii_pair, n_items, n_win, words, h->ii_win, 0);
             }
         }
     }
@@ -934,6 +941,15 @@ int ifr_fit_rp3beta(ifr_handle h, const int64_t *a_indptr, const int32_t *a_indi
     return rc;
 }
 
+int ifr_item_csr_layout(ifr_handle h, int *win_words, double *long_share)
+{
+    if (!h) return IFR_ERR_ARG;
+    if (h->mode != MODE_ITEM_CSR) return fail(h, IFR_ERR_STATE, "ifr_item_csr_layout: needs a CSR item matrix");
+    if (win_words) *win_words = h->ii_win != nullptr ? h->ii_win_words : 0;
+    if (long_share) *long_share = h->ii_long_frac;
+    return IFR_OK;
+}
+
 int ifr_item_fixed_point_shift(ifr_handle h, int *shift)
 {
     if (!h || !shift) return IFR_ERR_ARG;
@@ -996,7 +1012,7 @@ static int rank_topk_item_item(ifr_handle h, const int32_t *user_ids, int64_t n,
         if (h->ii_cptr_w != nullptr && h->ii_win != nullptr && (h->opt_csr_wave == 2 || (h->opt_csr_wave == 1 && h->ii_long_frac <= 0.003))) {
             rc = grow(h, &h->ws_long, &h->ws_long_bytes, sizeof(int32_t) * ((size_t)n + 1));
             if (rc) return rc;
-            p.cptr_w = h->ii_cptr_w; p.n_win = h->ii_n_win; p.m_win = h->ii_win;
+            p.cptr_w = h->ii_cptr_w; p.n_win = h->ii_n_win; p.m_win = h->ii_win; p.win_words = h->ii_win_words;
             p.long_cnt = (int *)h->ws_long; p.long_list = (int32_t *)h->ws_long + 1;
         }
         rc = prof_begin(h, s, &ev);

@@ -16,7 +16,8 @@ struct ItemItemParams {
     int64_t m_nnz;               //         entries in m_idx / m_val
     int fx_shift;                //         fixed-point scale 2^fx_shift
     int dbg;                     // dev-only ablation bits (handle option debug_mode)
-    const void *m_win;           //         [n_items][n_win] 16-byte window words (launch_build_win_words), or null
+    const void *m_win;           //         [n_items][n_win][win_words] 16-byte window words (launch_build_win_words), or null
+    int win_words;               //         1, 2 or 3
     const uint32_t *cptr_w;      //         [n_items][n_win + 1] entry offsets per 1024-column window (wave-per-user kernel), or null
     int n_win;
     int32_t *long_list;          //         users the wave-per-user kernel hands over to the workgroup kernel [n], and their count
@@ -50,7 +51,7 @@ int launch_merge_topk_f64(const double *part_scores, const int32_t *part_ids, in
                           float *out_scores, hipStream_t stream);
 int launch_item_sparse_topk(const ItemItemParams &p, int32_t *out_ids, float *out_scores, hipStream_t stream);
 int item_sparse_wave_windows(int n_items);
-int launch_build_win_words(const uint32_t *cw, const int64_t *cptr, int n_chunks, const uint2 *pair, int64_t n_rows, int n_win, void *out, hipStream_t s);
+int launch_build_win_words(const uint32_t *cw, const int64_t *cptr, int n_chunks, const uint2 *pair, int64_t n_rows, int n_win, int words, void *out, hipStream_t s);
 int item_sparse_wave_stride(int n_win);      // entries per row of the per-window offset table
 int launch_count_long_segments(const uint32_t *cw, int64_t n_rows, int n_win, unsigned long long *count, hipStream_t s);
 int launch_build_win_ptr(const int64_t *cptr, int n_chunks, const int32_t *idx, int64_t n_rows, int n_win, uint32_t *cw, hipStream_t s);

@@ -1025,7 +1025,6 @@ __global__ __launch_bounds__(SD_BLOCK, 4) void item_sparse_topk_kernel(ItemItemP
 // and a candidate buffer that overflows (mass ties).
 // ------------------------------------------------------------------------------------
 constexpr int SW_WIN = 1024;                            // columns per window
-constexpr int SW_PRE = 3;                               // entries per lane prefetched one window ahead
 constexpr int SW_CAND = 112;                            // the list + pending candidates
 constexpr int SW_ROWS = 4;                              // history rows per lane, at most (histories of up to 256 rows)
 constexpr int SW_MAXK = 32;                             // longest list of this kernel (longer ones: the workgroup kernel)
@@ -1054,8 +1053,12 @@ __device__ __forceinline__ void sw_lds_order()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
 }
 
+// WORDS = window words per (row, window): 1, 2 or 3 (3, 6 or 9 entries), chosen when the matrix is set from its segment
+// lengths; a lane keeps at most 4 / WORDS rows (registers).
+template <int WORDS>
 __global__ __launch_bounds__(64 * SW_WAVES) __attribute__((amdgpu_waves_per_eu(4, 4))) void item_sparse_wave_kernel(ItemItemParams p, int32_t *out_ids, float *out_scores)
 {
+    constexpr int RMAX = WORDS == 1 ? SW_ROWS : (WORDS == 2 ? 3 : 2);      // rows per lane, at most (registers: 4, 6, 6 words per buffer)
     __shared__ __attribute__((aligned(16))) SwLds lds[SW_WAVES];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     SwLds &S = lds[wave];
@@ -1074,7 +1077,7 @@ __global__ __launch_bounds__(64 * SW_WAVES) __attribute__((amdgpu_waves_per_eu(4
     auto hand_over = [&]() __attribute__((always_inline)) {
         if (lane == 0) p.long_list[atomicAdd(p.long_cnt, 1)] = (int32_t)i;
     };
-    if (he - hb > 64 * SW_ROWS || he == hb) { hand_over(); return; }      // (no history: only zero-sum columns to rank)
+    if (he - hb > 64 * RMAX || he == hb) { hand_over(); return; }      // (no history: only zero-sum columns to rank)
     const int m = (int)(he - hb);
 
     for (int w = lane; w < SW_WIN + 64; w += 64) S.tab[w] = 0.0;
@@ -1159,27 +1162,31 @@ __global__ __launch_bounds__(64 * SW_WAVES) __attribute__((amdgpu_waves_per_eu(4
         hj[r] = has_row[r] ? p.h_idx[hb + er] : 0;
         x[r] = has_row[r] ? ldexp((double)p.h_val[hb + er], p.fx_shift) : 0.0;
     }
-    struct Pre { u32x4 w[ROWS]; };
+    struct Pre { u32x4 w[ROWS][WORDS]; };
     // (unconditional loads at valid addresses: a lane without a row reads row 0 and ignores it)
     auto issue = [&](Pre &s, int c) __attribute__((always_inline)) {
         const int cc = min(c, n_win - 1);
 #pragma unroll
-        for (int r = 0; r < ROWS; ++r) s.w[r] = mw[(uint32_t)hj[r] * (uint32_t)n_win + (uint32_t)cc];
+        for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+            for (int j = 0; j < WORDS; ++j) s.w[r][j] = mw[((uint32_t)hj[r] * (uint32_t)n_win + (uint32_t)cc) * WORDS + j];
     };
     // A word always holds three (column, value) pairs: where the segment has fewer entries the spare pairs carry the
     // value 0 and the column of a real pair (or column 0).  Adding 0 changes nothing, and the exchange that follows
     // may well return the slot's sum to this lane instead of the lane whose entry it is -- whoever claims a slot reports
     // its column, which the slot number gives.  So the common window has no counts and no per-entry masks.
-    auto col_of = [&](const Pre &s, int r, int t) __attribute__((always_inline)) -> int { return (int)((s.w[r][3] >> (10 * t)) & 1023u); };
+    // (pair t of a row's segment: pair t % 3 of word t / 3)
+    auto col_of = [&](const Pre &s, int r, int t) __attribute__((always_inline)) -> int { return (int)((s.w[r][t / 3][3] >> (10 * (t % 3))) & 1023u); };
+    auto val_of = [&](const Pre &s, int r, int t) __attribute__((always_inline)) -> float { return __uint_as_float(s.w[r][t / 3][t % 3]); };
     // (a lane without a row keeps to a slot of its own behind the table: forty lanes adding zeros to row 0's slots would
     // queue up at the same LDS address)
     auto slot_of = [&](const Pre &s, int r, int t) __attribute__((always_inline)) -> int { return has_row[r] ? col_of(s, r, t) : SW_WIN + lane; };
-    auto more_of = [&](const Pre &s, int r) __attribute__((always_inline)) -> bool { return has_row[r] && (s.w[r][3] >> 30) != 0u; };
+    auto more_of = [&](const Pre &s, int r) __attribute__((always_inline)) -> bool { return has_row[r] && (s.w[r][0][3] >> 30) != 0u; };
     // entries 3 ... of a marked segment: [q0, q1) in the pair array
     auto rest_of = [&](int r, int c, uint32_t &q0, uint32_t &q1) __attribute__((always_inline)) {
         const uint32_t *const cw = p.cptr_w + (int64_t)hj[r] * sw_cw_stride(n_win) + SW_CW_LEAD;
         const uint32_t base = (uint32_t)p.cptr[(int64_t)hj[r] * (p.n_chunks + 1)];        // the row's first entry (< 2^30 entries in all)
-        q0 = base + cw[c] + 3u;
+        q0 = base + cw[c] + 3u * WORDS;
         q1 = base + cw[c + 1];
     };
     auto consume = [&](const Pre &s, int c, int colA) __attribute__((always_inline)) {
@@ -1187,8 +1194,8 @@ __global__ __launch_bounds__(64 * SW_WAVES) __attribute__((amdgpu_waves_per_eu(4
 #pragma unroll
         for (int r = 0; r < ROWS; ++r) {
 #pragma unroll
-            for (int t = 0; t < 3; ++t)
-                atomicAdd(&S.tab[slot_of(s, r, t)], fma(x[r], (double)__uint_as_float(s.w[r][t]), SD_MAGIC) - SD_MAGIC);
+            for (int t = 0; t < 3 * WORDS; ++t)
+                atomicAdd(&S.tab[slot_of(s, r, t)], fma(x[r], (double)val_of(s, r, t), SD_MAGIC) - SD_MAGIC);
             more |= more_of(s, r);
         }
         if (__builtin_expect(__any(more) != 0, 0)) {      // segments with more than three entries (rare on the matrices this kernel is picked for)
@@ -1219,19 +1226,19 @@ __global__ __launch_bounds__(64 * SW_WAVES) __attribute__((amdgpu_waves_per_eu(4
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
-        double v[ROWS][3];
+        double v[ROWS][3 * WORDS];
         bool look = false;
 #pragma unroll
         for (int r = 0; r < ROWS; ++r) {
 #pragma unroll
-            for (int t = 0; t < 3; ++t) v[r][t] = claim(slot_of(cur, r, t));
+            for (int t = 0; t < 3 * WORDS; ++t) v[r][t] = claim(slot_of(cur, r, t));
             look |= more_of(cur, r);
         }
         unsigned long long any = __ballot(look);          // (compares, not a maximum tree: fmax canonicalises its operands, an instruction each)
 #pragma unroll
         for (int r = 0; r < ROWS; ++r)
 #pragma unroll
-            for (int t = 0; t < 3; ++t) any |= __ballot(v[r][t] > tau_eff);
+            for (int t = 0; t < 3 * WORDS; ++t) any |= __ballot(v[r][t] > tau_eff);
         if (__builtin_expect(any == 0ull, 1)) return;
         const bool full = cnt == K;
 #pragma unroll
@@ -1252,20 +1259,20 @@ __global__ __launch_bounds__(64 * SW_WAVES) __attribute__((amdgpu_waves_per_eu(4
 #pragma unroll
             for (int r = 0; r < ROWS; ++r)
 #pragma unroll
-                for (int t = 0; t < 3; ++t) append(v[r][t] != 0.0 && v[r][t] > tau, v[r][t], colA + col_of(cur, r, t));   // (a zero passes the vote when the K-th sum is negative)
+                for (int t = 0; t < 3 * WORDS; ++t) append(v[r][t] != 0.0 && v[r][t] > tau, v[r][t], colA + col_of(cur, r, t));   // (a zero passes the vote when the K-th sum is negative)
         } else if ([&]() { bool nz = false;
 #pragma unroll
                            for (int r = 0; r < ROWS; ++r)
 #pragma unroll
-                               for (int t = 0; t < 3; ++t) nz |= v[r][t] != 0.0;
+                               for (int t = 0; t < 3 * WORDS; ++t) nz |= v[r][t] != 0.0;
                            return __any(nz) != 0; }()) {
             // short list: a lower bound of the window's K-th best sum by a bit-by-bit search over the order-preserving
             // high words of ALL claimed sums (ballot + popcount; excluded columns are looked up first)
-            uint32_t key[ROWS][3];
+            uint32_t key[ROWS][3 * WORDS];
 #pragma unroll
             for (int r = 0; r < ROWS; ++r)
 #pragma unroll
-                for (int t = 0; t < 3; ++t) {
+                for (int t = 0; t < 3 * WORDS; ++t) {
                     if (v[r][t] != 0.0 && n_ex != 0 && excluded(colA + col_of(cur, r, t))) v[r][t] = 0.0;
                     const uint32_t hi = (uint32_t)__double2hiint(v[r][t]);
                     key[r][t] = v[r][t] != 0.0 ? (hi ^ ((uint32_t)((int32_t)hi >> 31) | 0x80000000u)) : 0u;
@@ -1278,14 +1285,14 @@ __global__ __launch_bounds__(64 * SW_WAVES) __attribute__((amdgpu_waves_per_eu(4
 #pragma unroll
                 for (int r = 0; r < ROWS; ++r)
 #pragma unroll
-                    for (int t = 0; t < 3; ++t) n_at += __popcll(__ballot(key[r][t] >= trial));
+                    for (int t = 0; t < 3 * WORDS; ++t) n_at += __popcll(__ballot(key[r][t] >= trial));
                 if (n_at >= K) fl = trial;
             }
             const uint32_t floor_k = max(fl, 1u);
 #pragma unroll
             for (int r = 0; r < ROWS; ++r)
 #pragma unroll
-                for (int t = 0; t < 3; ++t) append(key[r][t] >= floor_k, v[r][t], colA + col_of(cur, r, t));
+                for (int t = 0; t < 3 * WORDS; ++t) append(key[r][t] >= floor_k, v[r][t], colA + col_of(cur, r, t));
         }
         if (!over && nq > cnt && (!full || nq - cnt >= SD_LAZY + K || nq + 24 > SW_CAND)) merge();   // lazy, like the kernel above
         tau_eff = cnt == K ? tau : -INFINITY;
@@ -1295,10 +1302,19 @@ __global__ __launch_bounds__(64 * SW_WAVES) __attribute__((amdgpu_waves_per_eu(4
         if (c + 1 < n_win && !over) window(c + 1, B, A);
     }
     };
-    if (m > 192) sweep(std::integral_constant<int, 4>{});
-    else if (m > 128) sweep(std::integral_constant<int, 3>{});
-    else if (m > 64) sweep(std::integral_constant<int, 2>{});
-    else sweep(std::integral_constant<int, 1>{});
+    if constexpr (RMAX >= 4) {
+        if (m > 192) sweep(std::integral_constant<int, 4>{});
+        else if (m > 128) sweep(std::integral_constant<int, 3>{});
+        else if (m > 64) sweep(std::integral_constant<int, 2>{});
+        else sweep(std::integral_constant<int, 1>{});
+    } else if constexpr (RMAX >= 3) {
+        if (m > 128) sweep(std::integral_constant<int, 3>{});
+        else if (m > 64) sweep(std::integral_constant<int, 2>{});
+        else sweep(std::integral_constant<int, 1>{});
+    } else if constexpr (RMAX >= 2) {
+        if (m > 64) sweep(std::integral_constant<int, 2>{});
+        else sweep(std::integral_constant<int, 1>{});
+    } else sweep(std::integral_constant<int, 1>{});
     if (!over && nq > cnt) merge();
     // zero-sum columns (score 0 * col_scale) can still rank when the list is short or ends at or below zero: the sweep
     // over them lives in the workgroup kernel
@@ -1329,7 +1345,7 @@ __global__ void build_win_ptr_kernel(const int64_t *cptr, int nc1, const int32_t
 // the kernel fetches the rest from the pair array).  A segment with fewer than three entries fills the spare pairs with
 // the value 0 and the column of its first entry (an empty one: a column that depends on the row): the kernel treats all
 // three alike.
-__global__ void build_win_words_kernel(const uint32_t *cw, const int64_t *cptr, int nc1, const uint2 *pair, int64_t n_rows, int n_win, uint4 *out)
+__global__ void build_win_words_kernel(const uint32_t *cw, const int64_t *cptr, int nc1, const uint2 *pair, int64_t n_rows, int n_win, int words, uint4 *out)
 {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n_rows * n_win) return;
@@ -1338,40 +1354,48 @@ __global__ void build_win_words_kernel(const uint32_t *cw, const int64_t *cptr, 
     const uint32_t *row = cw + r * sw_cw_stride(n_win) + SW_CW_LEAD;
     const uint32_t q0 = row[c], q1 = row[c + 1];
     const int64_t base = cptr[r * nc1];
-    const int n = (int)(q1 - q0), cnt = n < 3 ? n : 3;
-    uint2 e[3] = {make_uint2(0u, 0u), make_uint2(0u, 0u), make_uint2(0u, 0u)};
-    for (int k = 0; k < cnt; ++k) {
-        e[k] = pair[base + q0 + k];
-        e[k].x -= (uint32_t)c * SW_WIN;
+    const int n = (int)(q1 - q0);
+    // the column the spare pairs point at: the segment's first entry (an empty segment: some column of the window, not
+    // the same one for every row)
+    const uint32_t spare = n > 0 ? pair[base + q0].x - (uint32_t)c * SW_WIN : (uint32_t)(r & (SW_WIN - 1));
+    for (int j = 0; j < words; ++j) {
+        uint2 e[3];
+        for (int k = 0; k < 3; ++k) {
+            const int q = 3 * j + k;
+            if (q < n) { e[k] = pair[base + q0 + q]; e[k].x -= (uint32_t)c * SW_WIN; }
+            else e[k] = make_uint2(spare, 0u);                        // (value +0.0f)
+        }
+        out[t * words + j] = make_uint4(e[0].y, e[1].y, e[2].y, e[0].x | (e[1].x << 10) | (e[2].x << 20) | (j == 0 && n > 3 * words ? 1u << 30 : 0u));
     }
-    if (cnt == 0) e[0].x = (uint32_t)(r & (SW_WIN - 1));              // (an empty segment: some column of the window, not the same one for every row)
-    for (int k = cnt; k < 3; ++k) e[k] = make_uint2(e[0].x, 0u);      // (value +0.0f)
-    out[t] = make_uint4(e[0].y, e[1].y, e[2].y, e[0].x | (e[1].x << 10) | (e[2].x << 20) | (n > 3 ? 1u << 30 : 0u));
 }
 
-int launch_build_win_words(const uint32_t *cw, const int64_t *cptr, int n_chunks, const uint2 *pair, int64_t n_rows, int n_win, void *out, hipStream_t s)
+int launch_build_win_words(const uint32_t *cw, const int64_t *cptr, int n_chunks, const uint2 *pair, int64_t n_rows, int n_win, int words, void *out, hipStream_t s)
 {
     const int64_t total = n_rows * n_win;
     if (total <= 0) return 0;
-    if (total >= ((int64_t)1 << 32)) return -1;
-    hipLaunchKernelGGL(build_win_words_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, cw, cptr, n_chunks + 1, pair, n_rows, n_win, (uint4 *)out);
+    if (words < 1 || words > 3 || total * words >= ((int64_t)1 << 32)) return -1;
+    hipLaunchKernelGGL(build_win_words_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, cw, cptr, n_chunks + 1, pair, n_rows, n_win, words, (uint4 *)out);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
 // (row, window) segments with more entries than a lane prefetches: the wave-per-user kernel walks those one load at a
 // time, so it only pays on matrices whose rows spread evenly over the windows
+// count[k]: segments with more than 3 (k + 1) entries, k = 0, 1, 2 (what one, two, three window words hold)
 __global__ void count_long_segments_kernel(const uint32_t *cw, int64_t n_rows, int n_win, unsigned long long *count)
 {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    bool is_long = false;
+    uint32_t len = 0;
     if (t < n_rows * n_win) {
         const int64_t r = t / n_win;
         const int c = (int)(t - r * n_win);
         const uint32_t *row = cw + r * sw_cw_stride(n_win) + SW_CW_LEAD;
-        is_long = row[c + 1] - row[c] > (uint32_t)SW_PRE;
+        len = row[c + 1] - row[c];
     }
-    const unsigned long long b = __ballot(is_long);
-    if ((threadIdx.x & 63) == 0 && b != 0ull) atomicAdd(count, (unsigned long long)__popcll(b));
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const unsigned long long b = __ballot(len > 3u * (uint32_t)(k + 1));
+        if ((threadIdx.x & 63) == 0 && b != 0ull) atomicAdd(count + k, (unsigned long long)__popcll(b));
+    }
 }
 
 int launch_count_long_segments(const uint32_t *cw, int64_t n_rows, int n_win, unsigned long long *count, hipStream_t s)
@@ -1420,7 +1444,11 @@ int launch_item_sparse_topk(const ItemItemParams &p, int32_t *out_ids, float *ou
         if (hipMemsetAsync(p.long_cnt, 0, sizeof(int), stream) != hipSuccess) return -3;
         ItemItemParams w = p;
         w.sp_cap = cap;
-        hipLaunchKernelGGL(item_sparse_wave_kernel, dim3((unsigned)((p.n + SW_WAVES - 1) / SW_WAVES)), dim3(64 * SW_WAVES), 0, stream, w, out_ids, out_scores);
+        const dim3 wgrid((unsigned)((p.n + SW_WAVES - 1) / SW_WAVES)), wblock(64 * SW_WAVES);
+        if (p.win_words == 1) hipLaunchKernelGGL((item_sparse_wave_kernel<1>), wgrid, wblock, 0, stream, w, out_ids, out_scores);
+        else if (p.win_words == 2) hipLaunchKernelGGL((item_sparse_wave_kernel<2>), wgrid, wblock, 0, stream, w, out_ids, out_scores);
+        else if (p.win_words == 3) hipLaunchKernelGGL((item_sparse_wave_kernel<3>), wgrid, wblock, 0, stream, w, out_ids, out_scores);
+        else return -1;
         const unsigned grid = (unsigned)(p.n < 2048 ? p.n : 2048);
         hipLaunchKernelGGL((item_sparse_topk_kernel<true, true>), dim3(grid), dim3(SD_BLOCK), 0, stream, w, out_ids, out_scores);
         return hipGetLastError() == hipSuccess ? 0 : -3;

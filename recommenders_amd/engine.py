@@ -281,6 +281,12 @@ class HipScorer:
         self._check(self._lib.ifr_item_fixed_point_shift(self._h, ctypes.byref(sh)))
         return sh.value
 
+    def item_csr_layout(self):
+        """(window words per row and window of the wave-per-user kernel's table -- 0: not built --, share of longer segments)."""
+        w, f = ctypes.c_int(0), ctypes.c_double(0.0)
+        self._check(self._lib.ifr_item_csr_layout(self._h, ctypes.byref(w), ctypes.byref(f)))
+        return w.value, f.value
+
     def set_exclusion_csr(self, indptr, indices):
         self.exclusion_source = None     # ranking_eval notes here which matrix the device copy was made from
         pp, kp = self._any_ptr(indptr, np.int64)

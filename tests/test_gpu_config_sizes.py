@@ -108,3 +108,38 @@ def test_c5_shape_csr_125000_items_256_neighbours_bit_exact(torch, cand_cap, wav
         np.testing.assert_array_equal(scores.cpu().numpy(), o_sc)
         np.testing.assert_allclose(per_user.cpu().numpy()[:, :3], o_met[:, :3], atol=1e-12)
     sc.close()
+
+
+@pytest.mark.parametrize("nnz,words", [(500, 2), (1000, 3)])
+def test_c5_range_more_neighbours_two_and_three_window_words(torch, nnz, words):
+    """SURVEY.md names 100 ... 1000 neighbours per row for C5.  With 500 / 1000 evenly spread neighbours a (row,
+    1024-column window) segment holds up to 6 / 9 entries: the wave-per-user kernel's table takes two / three 16-byte
+    words per segment (and a lane three / two history rows).  Histories of 1 ... 400 rows: one to three rows per lane
+    and the hand-over to the workgroup kernel."""
+    from recommenders_amd import HipScorer, synth
+    n_items = 125_000
+    rng = np.random.default_rng(33 + words)
+    m_ptr, m_idx, m_val = synth.sparse_item_matrix(rng, n_items, nnz)
+    lengths = [int(v) for v in rng.integers(3, 70, 120)] + [1, 64, 65, 100, 128, 129, 160, 192, 193, 300, 400, 0]
+    h_ptr, h_idx, t_ptr, t_idx = _histories(rng, lengths, np.arange(n_items), n_items)
+    cnt = np.diff(h_ptr)
+    h_val = np.repeat((1.0 / np.maximum(cnt, 1)).astype(np.float32), cnt)
+    col_scale = (1.0 / rng.integers(1, 3000, n_items) ** 0.7).astype(np.float32)
+    sc = HipScorer(0)
+    sc.set_item_matrix_csr(m_ptr, m_idx, m_val, n_items, col_scale)
+    got_words, long_share = sc.item_csr_layout()
+    assert got_words == words and long_share <= 0.003
+    sc.set_history_csr(h_ptr, h_idx, h_val)
+    sc.set_exclusion_csr(h_ptr, h_idx)
+    sc.set_truth_csr(t_ptr, t_idx)
+    users = np.arange(len(lengths), dtype=np.int32)
+    shift = sc.item_fixed_point_shift()
+    for K in (10, 32):
+        o_ids, o_sc, _, _ = orc.c_ranking_eval_item(None, (m_ptr, m_idx, m_val), shift, n_items, col_scale, h_ptr, h_idx, h_val,
+                                                    users, h_ptr, h_idx, t_ptr, t_idx, [K], False, K, n_threads=8)
+        for wave in (1, 0):
+            sc.set_option("csr_wave", wave)
+            ids, scores = sc.rank_topk(users, K)
+            np.testing.assert_array_equal(ids.cpu().numpy(), o_ids)
+            np.testing.assert_array_equal(scores.cpu().numpy(), o_sc)
+    sc.close()
