@@ -825,6 +825,11 @@ int ifr_set_item_matrix_csr(ifr_handle h, const int64_t *indptr, const int32_t *
                 int words = 1;
                 while (words < 3 && (double)n_long[words - 1] / n_seg > 0.003) ++words;
                 if ((double)n_long[words - 1] / n_seg > 0.003) words = 1;
+                // (two / three words cost a lane two / three loads and six / nine LDS adds + exchanges per window whatever the
+                // segment holds: only where the segments are reasonably full -- 2 / 4 entries on average -- does that beat
+                // the workgroup kernel, whose work follows the entries)
+                const double mean_len = (double)nnz / n_seg;
+                if ((words == 2 && mean_len < 2.0) || (words == 3 && mean_len < 4.0)) words = 1;
                 h->ii_win_words = words;
                 h->ii_long_frac = (double)n_long[words - 1] / n_seg;
                 // the window words that kernel reads: where they stay within twice the entries' own bytes (or 256 MB) and 4 GB
