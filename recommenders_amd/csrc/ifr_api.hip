@@ -839,6 +839,9 @@ int ifr_set_item_matrix_csr(ifr_handle h, const int64_t *indptr, const int32_t *
                     hipMalloc(&h->ii_win, win_bytes) == hipSuccess)
                     lrc = ifr::launch_build_win_words(h->ii_cptr_w, h->ii_cptr, n_chunks, (const uint2 *)h->ii_pair, n_items, n_win, words, h->ii_win, 0);
             }
+            // (these two tables are optional: an allocation that failed must not linger as the runtime's last error and
+            // make the next launch look broken)
+            if (h->ii_cptr_w == nullptr || h->ii_win == nullptr) (void)hipGetLastError();
         }
     }
     if (lrc || hipDeviceSynchronize() != hipSuccess ||
