@@ -470,14 +470,14 @@ def main():
         # variant of the path is measured by the driver's own run, with its own roofline and CPU parity sample.
         plan = []
         if world == 1:
-            plan += [("c2_auc", "c2_wmf_ml20m", 5, 2, dict(auc=True, cpu_sample=4096)),
-                     ("c2_top100", "c2_wmf_ml20m", 5, 2, dict(topk=100, cpu_sample=4096)),
-                     ("c2_k200", "c2_wmf_ml20m", 5, 2, dict(k=200, cpu_sample=4096))]
+            plan += [("c2_auc", "c2_wmf_ml20m", 10, 3, dict(auc=True, cpu_sample=4096)),
+                     ("c2_top100", "c2_wmf_ml20m", 10, 3, dict(topk=100, cpu_sample=4096)),
+                     ("c2_k200", "c2_wmf_ml20m", 10, 3, dict(k=200, cpu_sample=4096))]
         plan += [("c3_mf_shard", "c3_mf_shard", 2, 1, {})]
         if world == 1:
             plan += [("c4_ease_mind", "c4_ease_mind", 3, 1, {}),
                      ("c4_ease_mind_f64", "c4_ease_mind", 2, 1, dict(item_f64=True, cpu_sample=512)),
-                     ("c5_rp3_ebnerd", "c5_rp3_ebnerd", 3, 1, {})]
+                     ("c5_rp3_ebnerd", "c5_rp3_ebnerd", 6, 2, {})]
         for name, cfg_name, k_steps, k_warm, over in plan:
             torch.cuda.empty_cache()
             r = run_config(cfg_name, args, k_steps, k_warm, world, rank, dev, D, with_cpu, variant(args, cfg_name, **over))
