@@ -59,7 +59,7 @@ const char *ifr_last_error(ifr_handle h);
  * "wide_chunk_cap", "wide_stats": tuning / statistics of that path; "item_f64": see ifr_fit_ease (none of these
  * changes a result);
  * "csr_wave": CSR top-K kernel choice -- 0 = the workgroup-per-user kernel only; 1 (default) = one wave per user where
- * the history has at most 256 rows (192 / 128 rows with two / three words per segment; the rest handed to the workgroup
+ * the history has at most 512 rows (192 / 128 rows with two / three words per segment; the rest handed to the workgroup
  * kernel; needs the kernel's side table of one to three 16-byte words -- three entries each -- per matrix row and
  * 1024-column window, built when it stays within twice the entries' bytes / 256 MB), IF at most 0.3 % of the matrix's
  * (row, 1024-column window) segments hold more entries than those words (the word count is chosen and the share

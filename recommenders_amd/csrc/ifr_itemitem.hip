@@ -1020,13 +1020,14 @@ __global__ __launch_bounds__(SD_BLOCK, 4) void item_sparse_topk_kernel(ItemItemP
 // workgroup of its own (with four users per workgroup the LDS of three finished waves waited for the slowest: K = 32
 // 17 % slower).  Arithmetic, exchange-claim selection, lazy merges and the exact-domain ranking are those of the kernel
 // above (same results bit for bit).
-// What this kernel does not serve it hands to the workgroup kernel through p.long_list: histories beyond 256 rows,
+// What this kernel does not serve it hands to the workgroup kernel through p.long_list: histories beyond 512 rows (one-word layout),
 // users whose list ends short or with a K-th sum <= 0 (zero-sum columns may rank: the sweep over them lives there),
 // and a candidate buffer that overflows (mass ties).
 // ------------------------------------------------------------------------------------
 constexpr int SW_WIN = 1024;                            // columns per window
 constexpr int SW_CAND = 112;                            // the list + pending candidates
 constexpr int SW_ROWS = 4;                              // history rows per lane, at most (histories of up to 256 rows)
+constexpr int SW_TAIL = 256;                            // history rows beyond four per lane that the one-word sweep still takes (two dependent loads per window each)
 constexpr int SW_MAXK = 32;                             // longest list of this kernel (longer ones: the workgroup kernel)
 constexpr int SW_EXL = 32;                              // exclusion row entries kept in LDS
 constexpr int SW_WAVES = 1;                             // users (waves) per workgroup
@@ -1077,7 +1078,8 @@ __global__ __launch_bounds__(64 * SW_WAVES) __attribute__((amdgpu_waves_per_eu(4
     auto hand_over = [&]() __attribute__((always_inline)) {
         if (lane == 0) p.long_list[atomicAdd(p.long_cnt, 1)] = (int32_t)i;
     };
-    if (he - hb > 64 * RMAX || he == hb) { hand_over(); return; }      // (no history: only zero-sum columns to rank)
+    // (one-word layout: up to SW_TAIL more rows ride along without a lane of their own, see the sweep)
+    if (he - hb > 64 * RMAX + (WORDS == 1 ? SW_TAIL : 0) || he == hb) { hand_over(); return; }      // (no history: only zero-sum columns to rank)
     const int m = (int)(he - hb);
 
     for (int w = lane; w < SW_WIN + 64; w += 64) S.tab[w] = 0.0;
@@ -1183,12 +1185,19 @@ __global__ __launch_bounds__(64 * SW_WAVES) __attribute__((amdgpu_waves_per_eu(4
     auto slot_of = [&](const Pre &s, int r, int t) __attribute__((always_inline)) -> int { return has_row[r] ? col_of(s, r, t) : SW_WIN + lane; };
     auto more_of = [&](const Pre &s, int r) __attribute__((always_inline)) -> bool { return has_row[r] && (s.w[r][0][3] >> 30) != 0u; };
     // entries 3 ... of a marked segment: [q0, q1) in the pair array
-    auto rest_of = [&](int r, int c, uint32_t &q0, uint32_t &q1) __attribute__((always_inline)) {
-        const uint32_t *const cw = p.cptr_w + (int64_t)hj[r] * sw_cw_stride(n_win) + SW_CW_LEAD;
-        const uint32_t base = (uint32_t)p.cptr[(int64_t)hj[r] * (p.n_chunks + 1)];        // the row's first entry (< 2^30 entries in all)
+    auto rest_of_row = [&](int row, int c, uint32_t &q0, uint32_t &q1) __attribute__((always_inline)) {
+        const uint32_t *const cw = p.cptr_w + (int64_t)row * sw_cw_stride(n_win) + SW_CW_LEAD;
+        const uint32_t base = (uint32_t)p.cptr[(int64_t)row * (p.n_chunks + 1)];        // the row's first entry (< 2^30 entries in all)
         q0 = base + cw[c] + 3u * WORDS;
         q1 = base + cw[c + 1];
     };
+    auto rest_of = [&](int r, int c, uint32_t &q0, uint32_t &q1) __attribute__((always_inline)) { rest_of_row(hj[r], c, q0, q1); };
+    // Histories a little beyond four rows per lane (one-word layout only; 0.4 % of C5's users, who cost the workgroup
+    // kernel 7 % of the call): the rows past 256 have no lane and no prefetch -- their words are fetched inside the
+    // window, for the adds and again for the exchanges -- and such a window always takes the slow path.
+    constexpr bool TAIL = WORDS == 1 && ROWS == RMAX;
+    const int tail0 = 64 * ROWS;
+    const bool has_tail = TAIL && m > tail0;
     auto consume = [&](const Pre &s, int c, int colA) __attribute__((always_inline)) {
         bool more = false;
 #pragma unroll
@@ -1197,6 +1206,24 @@ __global__ __launch_bounds__(64 * SW_WAVES) __attribute__((amdgpu_waves_per_eu(4
             for (int t = 0; t < 3 * WORDS; ++t)
                 atomicAdd(&S.tab[slot_of(s, r, t)], fma(x[r], (double)val_of(s, r, t), SD_MAGIC) - SD_MAGIC);
             more |= more_of(s, r);
+        }
+        if (TAIL && has_tail) {
+            for (int er = tail0 + lane; er < m; er += 64) {
+                const int row = p.h_idx[hb + er];
+                const double xt = ldexp((double)p.h_val[hb + er], p.fx_shift);
+                const u32x4 w = mw[(uint32_t)row * (uint32_t)n_win + (uint32_t)c];
+#pragma unroll
+                for (int t = 0; t < 3; ++t)
+                    atomicAdd(&S.tab[(w[3] >> (10 * t)) & 1023u], fma(xt, (double)__uint_as_float(w[t]), SD_MAGIC) - SD_MAGIC);
+                if ((w[3] >> 30) != 0u) {
+                    uint32_t q0, q1;
+                    rest_of_row(row, c, q0, q1);
+                    for (uint32_t q = q0; q < q1; ++q) {
+                        const uint2 e2 = rp[q];
+                        atomicAdd(&S.tab[(int)e2.x - colA], fma(xt, (double)__uint_as_float(e2.y), SD_MAGIC) - SD_MAGIC);
+                    }
+                }
+            }
         }
         if (__builtin_expect(__any(more) != 0, 0)) {      // segments with more than three entries (rare on the matrices this kernel is picked for)
 #pragma unroll
@@ -1239,6 +1266,7 @@ __global__ __launch_bounds__(64 * SW_WAVES) __attribute__((amdgpu_waves_per_eu(4
         for (int r = 0; r < ROWS; ++r)
 #pragma unroll
             for (int t = 0; t < 3 * WORDS; ++t) any |= __ballot(v[r][t] > tau_eff);
+        if (TAIL && has_tail) any = ~0ull;
         if (__builtin_expect(any == 0ull, 1)) return;
         const bool full = cnt == K;
 #pragma unroll
@@ -1294,7 +1322,36 @@ __global__ __launch_bounds__(64 * SW_WAVES) __attribute__((amdgpu_waves_per_eu(4
 #pragma unroll
                 for (int t = 0; t < 3 * WORDS; ++t) append(key[r][t] >= floor_k, v[r][t], colA + col_of(cur, r, t));
         }
-        if (!over && nq > cnt && (!full || nq - cnt >= SD_LAZY + K || nq + 24 > SW_CAND)) merge();   // lazy, like the kernel above
+        if (TAIL && has_tail && !over) {
+            // the rows without a lane: once the lanes' own rows have filled the list (else the workgroup kernel takes the user)
+            if (nq > cnt && cnt < K) merge();
+            if (cnt < K) over = true;
+            for (int er0 = tail0; er0 < m && !over; er0 += 64) {
+                const int er = er0 + lane;
+                const bool in = er < m;
+                const int row = in ? p.h_idx[hb + er] : 0;
+                const u32x4 w = mw[(uint32_t)row * (uint32_t)n_win + (uint32_t)c];
+#pragma unroll
+                for (int t = 0; t < 3; ++t) {
+                    const int col = (int)((w[3] >> (10 * t)) & 1023u);
+                    const double vv = in ? claim(col) : 0.0;
+                    append(vv != 0.0 && vv > tau, vv, colA + col);
+                }
+                const bool mr = in && (w[3] >> 30) != 0u;
+                if (__any(mr)) {
+                    uint32_t q0 = 0, q1 = 0;
+                    if (mr) rest_of_row(row, c, q0, q1);
+                    for (uint32_t q = q0; __any(q < q1); ++q) {
+                        const bool inq = q < q1;
+                        const int col = inq ? (int)rp[q].x : 0;
+                        const double vv = inq ? claim(col - colA) : 0.0;
+                        append(vv != 0.0 && vv > tau, vv, col);
+                    }
+                }
+                if (!over && nq + 24 + 3 * 64 > SW_CAND && nq > cnt) merge();      // (room for the next 64 rows' candidates)
+            }
+        }
+        if (!over && nq > cnt && (cnt < K || nq - cnt >= SD_LAZY + K || nq + 24 > SW_CAND)) merge();   // lazy, like the kernel above
         tau_eff = cnt == K ? tau : -INFINITY;
     };
     for (int c = 0; c < n_win && !over; c += 2) {
