@@ -1025,7 +1025,7 @@ __global__ __launch_bounds__(SD_BLOCK, 4) void item_sparse_topk_kernel(ItemItemP
 // and a candidate buffer that overflows (mass ties).
 // ------------------------------------------------------------------------------------
 constexpr int SW_WIN = 1024;                            // columns per window
-constexpr int SW_CAND = 112;                            // the list + pending candidates
+constexpr int SW_CAND = 128;                            // the list + pending candidates (two per lane in the merge)
 constexpr int SW_ROWS = 4;                              // history rows per lane, at most (histories of up to 256 rows)
 constexpr int SW_TAIL = 256;                            // history rows beyond four per lane that the one-word sweep still takes (two dependent loads per window each)
 constexpr int SW_MAXK = 32;                             // longest list of this kernel (longer ones: the workgroup kernel)
@@ -1038,7 +1038,7 @@ constexpr int SW_CW_LEAD = 2, SW_CW_TAIL = 8;
 __host__ __device__ inline int sw_cw_stride(int n_win) { return (SW_CW_LEAD + n_win + 1 + SW_CW_TAIL + 3) & ~3; }
 
 struct SwLds {
-    double tab[SW_WIN + 64];                            // + a dummy slot per lane
+    double tab[SW_WIN];
     double cv[SW_CAND];
     int cc[SW_CAND];
     int exl[SW_EXL];
@@ -1082,7 +1082,7 @@ __global__ __launch_bounds__(64 * SW_WAVES) __attribute__((amdgpu_waves_per_eu(4
     if (he - hb > 64 * RMAX + (WORDS == 1 ? SW_TAIL : 0) || he == hb) { hand_over(); return; }      // (no history: only zero-sum columns to rank)
     const int m = (int)(he - hb);
 
-    for (int w = lane; w < SW_WIN + 64; w += 64) S.tab[w] = 0.0;
+    for (int w = lane; w < SW_WIN; w += 64) S.tab[w] = 0.0;
     if (ex_lds) for (int w = lane; w < (int)n_ex; w += 64) S.exl[w] = p.ex_idx[eb + w];
     auto excluded = [&](int col) __attribute__((always_inline)) -> bool {
         int64_t lo = 0, hi = n_ex;
@@ -1180,9 +1180,9 @@ __global__ __launch_bounds__(64 * SW_WAVES) __attribute__((amdgpu_waves_per_eu(4
     // (pair t of a row's segment: pair t % 3 of word t / 3)
     auto col_of = [&](const Pre &s, int r, int t) __attribute__((always_inline)) -> int { return (int)((s.w[r][t / 3][3] >> (10 * (t % 3))) & 1023u); };
     auto val_of = [&](const Pre &s, int r, int t) __attribute__((always_inline)) -> float { return __uint_as_float(s.w[r][t / 3][t % 3]); };
-    // (a lane without a row keeps to a slot of its own behind the table: forty lanes adding zeros to row 0's slots would
-    // queue up at the same LDS address)
-    auto slot_of = [&](const Pre &s, int r, int t) __attribute__((always_inline)) -> int { return has_row[r] ? col_of(s, r, t) : SW_WIN + lane; };
+    // (a lane without a row keeps to slot `lane` of the table -- forty lanes adding zeros to row 0's slots would queue up
+    // at the same LDS address -- and, like any lane, reports what an exchange there hands it under the SLOT's column)
+    auto slot_of = [&](const Pre &s, int r, int t) __attribute__((always_inline)) -> int { return has_row[r] ? col_of(s, r, t) : lane; };
     auto more_of = [&](const Pre &s, int r) __attribute__((always_inline)) -> bool { return has_row[r] && (s.w[r][0][3] >> 30) != 0u; };
     // entries 3 ... of a marked segment: [q0, q1) in the pair array
     auto rest_of_row = [&](int row, int c, uint32_t &q0, uint32_t &q1) __attribute__((always_inline)) {
@@ -1287,7 +1287,7 @@ __global__ __launch_bounds__(64 * SW_WAVES) __attribute__((amdgpu_waves_per_eu(4
 #pragma unroll
             for (int r = 0; r < ROWS; ++r)
 #pragma unroll
-                for (int t = 0; t < 3 * WORDS; ++t) append(v[r][t] != 0.0 && v[r][t] > tau, v[r][t], colA + col_of(cur, r, t));   // (a zero passes the vote when the K-th sum is negative)
+                for (int t = 0; t < 3 * WORDS; ++t) append(v[r][t] != 0.0 && v[r][t] > tau, v[r][t], colA + slot_of(cur, r, t));   // (a zero passes the vote when the K-th sum is negative)
         } else if ([&]() { bool nz = false;
 #pragma unroll
                            for (int r = 0; r < ROWS; ++r)
@@ -1301,7 +1301,7 @@ __global__ __launch_bounds__(64 * SW_WAVES) __attribute__((amdgpu_waves_per_eu(4
             for (int r = 0; r < ROWS; ++r)
 #pragma unroll
                 for (int t = 0; t < 3 * WORDS; ++t) {
-                    if (v[r][t] != 0.0 && n_ex != 0 && excluded(colA + col_of(cur, r, t))) v[r][t] = 0.0;
+                    if (v[r][t] != 0.0 && n_ex != 0 && excluded(colA + slot_of(cur, r, t))) v[r][t] = 0.0;
                     const uint32_t hi = (uint32_t)__double2hiint(v[r][t]);
                     key[r][t] = v[r][t] != 0.0 ? (hi ^ ((uint32_t)((int32_t)hi >> 31) | 0x80000000u)) : 0u;
                 }
@@ -1320,7 +1320,7 @@ __global__ __launch_bounds__(64 * SW_WAVES) __attribute__((amdgpu_waves_per_eu(4
 #pragma unroll
             for (int r = 0; r < ROWS; ++r)
 #pragma unroll
-                for (int t = 0; t < 3 * WORDS; ++t) append(key[r][t] >= floor_k, v[r][t], colA + col_of(cur, r, t));
+                for (int t = 0; t < 3 * WORDS; ++t) append(key[r][t] >= floor_k, v[r][t], colA + slot_of(cur, r, t));
         }
         if (TAIL && has_tail && !over) {
             // the rows without a lane: once the lanes' own rows have filled the list (else the workgroup kernel takes the user)
