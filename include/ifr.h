@@ -210,7 +210,7 @@ int ifr_read_eval_csr(ifr_handle h, int which, int64_t *indptr, int32_t *indices
  * ascending on ties.  out_ids/out_scores: dev [n][K]; unfilled slots (fewer than K
  * candidates) hold id -1 / score -inf.  user_ids: dev [n].
  * 1 <= K <= IFR_MAX_TOPK for dot-product models, IFR_MAX_TOPK_ITEM for dense item matrices, IFR_MAX_TOPK_ITEM_CSR for
- * CSR item matrices (K <= 32: histories of at most 256 rows by the wave-per-user kernel where the matrix suits it, see
+ * CSR item matrices (K <= 64: histories of at most 512 rows by the wave-per-user kernel where the matrix suits it, see
  * "csr_wave"; everything else by the workgroup-per-user kernel).  Dot-product models, K <= 16: lane-private
  * sorted lists, merged per user; the call is asynchronous on `stream`.  16 < K <= 100 (dot-product models): the same
  * kernel; a user's two 16-entry lists per item chunk (2 ... 8 chunks, about K / 12) hold the top K unless more than

@@ -520,7 +520,7 @@ __global__ __launch_bounds__(SD_BLOCK, 4) void item_sparse_topk_kernel(ItemItemP
     // at least ceil(K / 4) of its lanes at or above -- and the workgroup takes the SMALLEST of the four: 4 ceil(K / 4) >= K
     // distinct columns reach it.  (K <= 64: every wave's K-th best is a bound by itself, the largest is taken.)
     const int lazy = min(SD_LAZY + K, SD_LAZY_MAX);     // pending candidates that trigger a merge while the list is full
-    const bool split = K > 64;
+    const bool split = K > 32;                            // (measured: K = 64 unsplit ran slower than K = 100 split -- a wave rarely holds 64 candidates)
     const int Kw = split ? (K + SD_BLOCK / 64 - 1) / (SD_BLOCK / 64) : K;
 
     int64_t hb = 0, he = 0, eb = 0, ee = 0;
@@ -1028,7 +1028,7 @@ constexpr int SW_WIN = 1024;                            // columns per window
 constexpr int SW_CAND = 128;                            // the list + pending candidates (two per lane in the merge)
 constexpr int SW_ROWS = 4;                              // history rows per lane, at most (histories of up to 256 rows)
 constexpr int SW_TAIL = 256;                            // history rows beyond four per lane that the one-word sweep still takes (two dependent loads per window each)
-constexpr int SW_MAXK = 32;                             // longest list of this kernel (longer ones: the workgroup kernel)
+constexpr int SW_MAXK = 64;                             // longest list of this kernel (longer ones: the workgroup kernel)
 constexpr int SW_EXL = 32;                              // exclusion row entries kept in LDS
 constexpr int SW_WAVES = 1;                             // users (waves) per workgroup
 // the per-row table of entry offsets per window: T[SW_CW_LEAD + k] = offset of the row's first entry with column >= k * SW_WIN,
