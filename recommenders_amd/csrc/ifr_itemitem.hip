@@ -520,7 +520,7 @@ __global__ __launch_bounds__(SD_BLOCK, 4) void item_sparse_topk_kernel(ItemItemP
     // at least ceil(K / 4) of its lanes at or above -- and the workgroup takes the SMALLEST of the four: 4 ceil(K / 4) >= K
     // distinct columns reach it.  (K <= 64: every wave's K-th best is a bound by itself, the largest is taken.)
     const int lazy = min(SD_LAZY + K, SD_LAZY_MAX);     // pending candidates that trigger a merge while the list is full
-    const bool split = K > 32;                            // (measured: K = 64 unsplit ran slower than K = 100 split -- a wave rarely holds 64 candidates)
+    const bool split = K > 4;                             // (measured: splitting pays from K = 8 on, +2 % at K = 10, +8 % at K = 32; K = 64 unsplit ran slower than K = 100 split)
     const int Kw = split ? (K + SD_BLOCK / 64 - 1) / (SD_BLOCK / 64) : K;
 
     int64_t hb = 0, he = 0, eb = 0, ee = 0;
